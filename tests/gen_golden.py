@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REAL reference modules.
+
+Runs only in the build container (needs /root/reference); the fixtures it
+writes are committed, the reference never travels.  Weights are NOT stored:
+they are regenerated from seeds by tacotron2_amd.synth.
+
+    python tests/gen_golden.py
+
+Reference entry points exercised:
+  hifigan/models.py:112-174  Generator (load_state_dict with weight_g/weight_v,
+                             remove_weight_norm, forward on 3-D and 2-D input)
+  waveglow/glow.py:178-313   WaveGlow (remove_weightnorm, upsample, WN.forward,
+                             Invertible1x1Conv reverse) walked as infer() does at
+                             glow.py:251-295 with explicit noise, because infer()
+                             itself allocates torch.cuda tensors (glow.py:262-269)
+"""
+import copy
+import json
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+warnings.filterwarnings("ignore")
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("REFERENCE_ROOT", "/root/reference")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(REF, "waveglow"))
+
+from tacotron2_amd import synth  # noqa: E402
+
+GOLD = os.path.join(HERE, "golden")
+torch.manual_seed(0)
+torch.set_grad_enabled(False)
+
+
+def ref_generator(cfg, seed):
+    from hifigan import AttrDict
+    from hifigan.models import Generator
+
+    g = Generator(AttrDict(cfg))
+    sd = synth.hifigan_state(cfg, seed, weight_norm=True)
+    g.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    g.eval()
+    g.remove_weight_norm()
+    return g
+
+
+def hifigan_case(name, cfg, seed, T, mel_seed, slices=True):
+    g = ref_generator(cfg, seed)
+    mel = synth.synthetic_mel(T, mel_seed)
+    y3 = g(torch.from_numpy(mel)[None])  # [1,1,256T]
+    y2 = g(torch.from_numpy(mel))  # do_syn.py:391 passes 2-D -> [1,256T]
+    assert torch.equal(y3[0], y2)
+    out = {"wav": y3[0, 0].numpy(), "T": np.int32(T), "mel_seed": np.int32(mel_seed), "weight_seed": np.int32(seed)}
+    # per-stage tensors via forward hooks on the reference's own modules
+    acts = {}
+    hooks = [g.conv_pre.register_forward_hook(lambda m, i, o: acts.__setitem__("conv_pre", o))]
+    for i, up in enumerate(g.ups):
+        hooks.append(up.register_forward_hook(lambda m, i_, o, i=i: acts.__setitem__(f"ups.{i}", o)))
+    nk = g.num_kernels
+    for n, rb in enumerate(g.resblocks):
+        # clone: Generator.forward accumulates the MRF sum in place into the first block's output (models.py:159)
+        hooks.append(rb.register_forward_hook(lambda m, i_, o, n=n: acts.__setitem__(f"rb.{n}", o.clone())))
+    g(torch.from_numpy(mel)[None])
+    for h in hooks:
+        h.remove()
+    for i in range(g.num_upsamples):
+        st = sum(acts[f"rb.{i * nk + j}"] for j in range(nk)) / nk
+        acts[f"stage.{i}"] = st
+    for k, v in acts.items():
+        if k.startswith("rb."):
+            continue
+        a = v[0].numpy()
+        if slices and a.size > 70000:
+            # head / tail 32 columns + checksums keep the fixture small
+            out[f"{k}.head"] = a[:, :32].copy()
+            out[f"{k}.tail"] = a[:, -32:].copy()
+            out[f"{k}.sum"] = np.float64(a.astype(np.float64).sum())
+            out[f"{k}.abs"] = np.float64(np.abs(a.astype(np.float64)).sum())
+        else:
+            out[k] = a
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(name, "wav rms %.4f" % float(y3.pow(2).mean().sqrt()), "T", T)
+
+
+def hifigan_ragged(name, cfg, seed, lengths, mel_seed):
+    g = ref_generator(cfg, seed)
+    out = {"lengths": np.asarray(lengths, np.int32), "weight_seed": np.int32(seed), "mel_seed": np.int32(mel_seed)}
+    for b, T in enumerate(lengths):
+        mel = synth.synthetic_mel(int(T), mel_seed + b)
+        out[f"wav.{b}"] = g(torch.from_numpy(mel))[0].numpy()
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(name, lengths)
+
+
+def fold_case(name, cfg, seed):
+    """Folded-weight checksums incl. the ConvTranspose per-input-channel case."""
+    g = ref_generator(cfg, seed)
+    sd = g.state_dict()
+    out = {}
+    for k in ("conv_pre.weight", "ups.0.weight", "ups.3.weight", "resblocks.4.convs1.1.weight", "conv_post.weight"):
+        a = sd[k].numpy().astype(np.float64)
+        out[k + ".sum"] = np.float64(a.sum())
+        out[k + ".abs"] = np.float64(np.abs(a).sum())
+        out[k + ".head"] = sd[k].numpy().ravel()[:64].copy()
+    out["n_keys_folded"] = np.int32(len(sd))
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(name, "folded keys", len(sd))
+
+
+def waveglow_case(name, cfg, seed, T, B, mel_seed, noise_seed, sigma):
+    from glow import WaveGlow
+
+    m = WaveGlow(**cfg)
+    m = WaveGlow.remove_weightnorm(m)
+    st = synth.waveglow_state(cfg, seed)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
+    m.eval()
+    mel = np.stack([synth.synthetic_mel(T, mel_seed + b) for b in range(B)])
+    noise = synth.waveglow_noise(cfg, B, T, noise_seed)
+    # walk of WaveGlow.infer (glow.py:251-295) on the reference's own sub-modules
+    spect = m.upsample(torch.from_numpy(mel))
+    time_cutoff = m.upsample.kernel_size[0] - m.upsample.stride[0]
+    spect = spect[:, :, :-time_cutoff]
+    spect = spect.unfold(2, m.n_group, m.n_group).permute(0, 2, 1, 3)
+    spect = spect.contiguous().view(spect.size(0), spect.size(1), -1).permute(0, 2, 1)
+    audio = sigma * torch.from_numpy(noise[0])
+    ni = 1
+    out = {"T": np.int32(T), "B": np.int32(B), "sigma": np.float32(sigma), "weight_seed": np.int32(seed),
+           "mel_seed": np.int32(mel_seed), "noise_seed": np.int32(noise_seed)}
+    small = cfg["WN_config"]["n_channels"] <= 64
+    if small:
+        out["spect"] = spect.contiguous().numpy()
+    else:
+        out["spect.head"] = spect[:, :, :16].contiguous().numpy()
+        out["spect.sum"] = np.float64(spect.double().sum())
+    for k in reversed(range(m.n_flows)):
+        n_half = int(audio.size(1) / 2)
+        audio_0 = audio[:, :n_half, :]
+        audio_1 = audio[:, n_half:, :]
+        output = m.WN[k]((audio_0, spect))
+        s = output[:, n_half:, :]
+        b = output[:, :n_half, :]
+        audio_1 = (audio_1 - b) / torch.exp(s)
+        audio = torch.cat([audio_0, audio_1], 1)
+        audio = m.convinv[k](audio, reverse=True)
+        out[f"flow.{k}"] = audio.contiguous().numpy()
+        if k == m.n_flows - 1:
+            out["wn_out.last"] = output.contiguous().numpy()
+        if k % m.n_early_every == 0 and k > 0:
+            audio = torch.cat((sigma * torch.from_numpy(noise[ni]), audio), 1)
+            ni += 1
+    audio = audio.permute(0, 2, 1).contiguous().view(audio.size(0), -1)
+    out["wav"] = audio.numpy()
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(name, "wav rms %.4f" % float(audio.pow(2).mean().sqrt()), "max %.3f" % float(audio.abs().max()))
+
+
+def pcm_case(name):
+    """D2: 32768*y -> astype('int16') exactly as do_syn.py:389-394 executes it (numpy on host)."""
+    d = np.load(os.path.join(GOLD, "hifigan_v1_T64.npz"))
+    y = torch.from_numpy(d["wav"])
+    audio = 32768.0 * y
+    pcm = audio.cpu().numpy().astype("int16")
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), pcm=pcm)
+    print(name, pcm[:8])
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    v1 = json.load(open(os.path.join(REF, "hifigan", "config.json")))
+    hifigan_case("hifigan_v1_T64", v1, 0, 64, 1234)
+    hifigan_case("hifigan_v1_T500", v1, 0, 500, 1234)
+    small = copy.deepcopy(v1)
+    small["upsample_initial_channel"] = 64
+    hifigan_case("hifigan_c64_T48", small, 1, 48, 77, slices=False)
+    hifigan_ragged("hifigan_v1_ragged", v1, 0, [40, 52, 64], 4321)
+    fold_case("hifigan_v1_fold", v1, 0)
+    wg64 = copy.deepcopy(synth.WAVEGLOW_512)
+    wg64["WN_config"]["n_channels"] = 64
+    waveglow_case("waveglow_c64_T16", wg64, 0, 16, 2, 1234, 1234, 0.666)
+    waveglow_case("waveglow_c512_T16", synth.WAVEGLOW_512, 0, 16, 1, 1234, 1234, 0.666)
+    wg256 = copy.deepcopy(synth.WAVEGLOW_512)
+    wg256["WN_config"]["n_channels"] = 256  # the repo's own waveglow/config.json:37 width
+    waveglow_case("waveglow_c256_T64", wg256, 0, 64, 1, 1234, 1234, 0.666)
+    pcm_case("pcm16_v1_T64")
+
+
+if __name__ == "__main__":
+    main()
