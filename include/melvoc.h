@@ -1,0 +1,160 @@
+/*
+ * melvoc.h -- C ABI of libmelvoc.so: MI355X (gfx950) mel-spectrogram -> waveform vocoding.
+ *
+ * The reference (gerard-bailly/tacotron2) has no FFI: its vocoder path is two Python
+ * nn.Module forward functions called by duck typing.  Each entry point below names the
+ * reference interface it stands in for (paths relative to the reference repository); the
+ * Python classes in tacotron2_amd/ keep those call signatures and bind these symbols with
+ * ctypes.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / C++ types cross this boundary.
+ *   - every function returns 0 or a negative MV_E* code; mv_last_error() gives the message of
+ *     the calling thread's last failure.  Kernels never abort().
+ *   - `*_forward/_infer` are asynchronous on the given hipStream_t (void* stream; NULL = the
+ *     default stream) and perform no allocation, no host<->device copy and no synchronisation.
+ *     The caller owns mel, lengths, noise, output and workspace (device memory).
+ *   - a handle owns only its repacked weights; it is bound to the device it was created on and
+ *     is not re-entrant (callers serialise calls on one handle; distinct handles are independent).
+ *   - the library needs a gfx950 device: there is no CPU fallback (mv_backend() == 1 always).
+ */
+#ifndef MELVOC_H
+#define MELVOC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MV_API __attribute__((visibility("default")))
+
+#define MV_OK 0
+#define MV_EINVAL (-1)   /* bad argument / shape / config */
+#define MV_ENOTFOUND (-2) /* a required weight tensor is missing */
+#define MV_EHIP (-3)     /* a HIP runtime call failed */
+#define MV_ENOMEM (-4)   /* workspace too small */
+#define MV_EUNSUPPORTED (-5)
+
+/* arithmetic of the MFMA-mapped convolutions */
+#define MV_PREC_FP32 0 /* f32 operands, v_mfma_f32_16x16x4_f32 (exact fp32 fma chains) */
+#define MV_PREC_BF16 1 /* bf16 operands, fp32 accumulate, fp32 residual stream (v_mfma_f32_16x16x32_bf16) */
+
+/* output sample formats of mv_hifigan_forward / mv_waveglow_infer */
+#define MV_OUT_F32 0   /* float32 in (-1,1), what Generator.forward / WaveGlow.infer return */
+#define MV_OUT_PCM16 1 /* int16 = (int16)(int32)(32768.0f * y): do_syn.py:11,389-394 (truncate, no clip) */
+
+typedef struct mv_handle_s* mv_handle;
+
+/* One named host tensor (float32, C-contiguous) in the reference's own layout:
+ * Conv1d weight [Cout][Cin][K], ConvTranspose1d weight [Cin][Cout][K], bias [Cout].
+ * Names are the reference's state_dict keys; a weight may be given folded ("x.weight") or as
+ * the weight-norm pair ("x.weight_g" [dim0,1,1] + "x.weight_v"), folded here as
+ * w = g * v / ||v|| over dims (1,2) per dim-0 index (torch.nn.utils.remove_weight_norm,
+ * hifigan/models.py:167-174, waveglow/glow.py:297-313). */
+typedef struct mv_tensor {
+    const char* name;
+    const float* data;
+    int ndim;
+    int64_t shape[4];
+} mv_tensor;
+
+/* hifigan/config.json keys read by Generator.__init__ (hifigan/models.py:113-147). */
+typedef struct mv_hifigan_cfg {
+    int num_mels;                 /* 80 */
+    int upsample_initial_channel; /* 512 */
+    int num_upsamples;            /* 4 */
+    int upsample_rates[8];        /* 8,8,2,2 */
+    int upsample_kernel_sizes[8]; /* 16,16,4,4 */
+    int num_kernels;              /* 3 */
+    int resblock_kernel_sizes[8]; /* 3,7,11 */
+    int resblock_dilations[8][3]; /* 1,3,5 each */
+} mv_hifigan_cfg;
+
+/* waveglow/config.json "waveglow_config" (WaveGlow.__init__, waveglow/glow.py:179-205). */
+typedef struct mv_waveglow_cfg {
+    int n_mel_channels; /* 80 */
+    int n_flows;        /* 12 */
+    int n_group;        /* 8 */
+    int n_early_every;  /* 4 */
+    int n_early_size;   /* 2 */
+    int n_layers;       /* WN_config.n_layers 8 */
+    int n_channels;     /* WN_config.n_channels 256 (repo config) / 512 (waveglow_NEB.pt) */
+    int kernel_size;    /* WN_config.kernel_size 3 */
+} mv_waveglow_cfg;
+
+/* 1 = gfx950 HIP kernels.  (0 would be a CPU backend; this library has none.) */
+MV_API int mv_backend(void);
+
+/* Message of the calling thread's last error ("" if none). */
+MV_API const char* mv_last_error(void);
+
+/* Replaces: Generator(h) + load_state_dict(ckpt["generator"]) + eval() + remove_weight_norm()
+ * + .to(device)   (do_syn.py:155-169, hifigan/models.py:113-147,167-174).
+ * Folds weight-norm, repacks every convolution into MFMA fragment order and uploads it to
+ * HIP device `device`.  `precision` is MV_PREC_*. */
+MV_API int mv_hifigan_create(const mv_hifigan_cfg* cfg, const mv_tensor* weights, int n_weights, int device,
+                      int precision, mv_handle* out);
+
+/* Replaces: Generator.forward (hifigan/models.py:149-165) as called at do_syn.py:278,391 and
+ * do_tts.py:351.
+ *   mel      device float32 [B][num_mels][Tmax], C-contiguous (the reference's layout)
+ *   lengths  device int32 [B] true frame counts (<= Tmax) or NULL (all Tmax).  Every layer
+ *            zero-pads at each sequence's own end, so row b equals the reference's batch-1
+ *            output for mel[b, :, :lengths[b]]; samples past lengths[b]*hop are written as 0.
+ *   wav      device [B][Tmax*hop], float32 (MV_OUT_F32) or int16 (MV_OUT_PCM16); hop = prod(rates)
+ *   workspace  device scratch of at least mv_workspace_bytes(h, B, Tmax) bytes, 256-byte aligned */
+MV_API int mv_hifigan_forward(mv_handle h, const float* mel, const int32_t* lengths, int B, int Tmax, void* wav,
+                       int out_format, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Replaces: torch.load(path)['model'] + WaveGlow.remove_weightnorm + .cuda().eval()
+ * (do_syn.py:147-150, waveglow/glow.py:179-205,297-313).  W^-1 of every Invertible1x1Conv is
+ * computed here once in fp32 (glow.py:89-95 caches it on first use). */
+MV_API int mv_waveglow_create(const mv_waveglow_cfg* cfg, const mv_tensor* weights, int n_weights, int device,
+                       int precision, mv_handle* out);
+
+/* Replaces: WaveGlow.infer (waveglow/glow.py:251-295) as called at do_syn.py:276,389 and
+ * do_tts.py:349.  The kernels never draw random numbers: the caller passes the unit-variance
+ * normal tensors in the reference's draw order (glow.py:262-271, 287-292):
+ *   noise[0]      device float32 [B][n_remaining_channels][L]   (L = Tmax*256/n_group)
+ *   noise[1..]    device float32 [B][n_early_size][L], one per early-output flow in the order the
+ *                 inverse loop meets them (k = 8 then k = 4 for the 12-flow model)
+ *   n_noise       number of entries (1 + number of early outputs)
+ *   wav           device [B][Tmax*256], sample = l*n_group + channel (glow.py:294) */
+MV_API int mv_waveglow_infer(mv_handle h, const float* mel, const int32_t* lengths, int B, int Tmax,
+                      const float* const* noise, int n_noise, float sigma, void* wav, int out_format,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* Scratch bytes mv_*_forward/_infer need for a [B][*][Tmax] batch (either handle kind). */
+MV_API size_t mv_workspace_bytes(mv_handle h, int B, int Tmax);
+
+/* Samples produced per mel frame (256 for both reference vocoders). */
+MV_API int mv_hop(mv_handle h);
+
+/* Algorithmic multiply-accumulates per mel frame of the model behind `h` (SURVEY.md §8a totals). */
+MV_API double mv_macs_per_frame(mv_handle h);
+
+/* Replaces: garbage collection of the Python module. */
+MV_API void mv_destroy(mv_handle h);
+
+/* Replaces: `32768.0 * y` -> .cpu().numpy().astype('int16') (do_syn.py:11,389-394) for a float32
+ * device buffer of n samples, on device. */
+MV_API int mv_pcm16(const float* wav, size_t n, int16_t* pcm, void* stream);
+
+/* ---- test hooks: single layers through the same kernels the forward path launches ----------
+ * No counterpart in the reference; they let tests/ compare one convolution against the oracle.
+ *   x   device float32 channels-last [B][L][Cin]   y  device float32 channels-last [B][Lout][Cout]
+ *   w/bias host float32 in the reference layout (Conv1d [Cout][Cin][K]; ConvTranspose1d
+ *   [Cin][Cout][K]).  `pre_slope` is the leaky_relu slope applied to x first (1.0 = none). */
+MV_API int mv_test_conv1d(const float* x, const int32_t* lengths, int B, int L, int Cin, const float* w,
+                   const float* bias, int Cout, int K, int dilation, float pre_slope, int precision, float* y,
+                   void* stream);
+MV_API int mv_test_conv_transpose1d(const float* x, const int32_t* lengths, int B, int L, int Cin, const float* w,
+                             const float* bias, int Cout, int K, int stride, int padding, float pre_slope,
+                             int precision, float* y, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MELVOC_H */

@@ -1,0 +1,198 @@
+"""ctypes binding of libmelvoc.so (include/melvoc.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails the
+caller gets an exception, never a silent PyTorch path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmelvoc.so")
+
+PREC_FP32, PREC_BF16 = 0, 1
+OUT_F32, OUT_PCM16 = 0, 1
+PRECISIONS = {"fp32": PREC_FP32, "float32": PREC_FP32, "bf16": PREC_BF16, "bfloat16": PREC_BF16}
+
+EXPORTS = (
+    "mv_backend", "mv_last_error", "mv_hifigan_create", "mv_hifigan_forward", "mv_waveglow_create",
+    "mv_waveglow_infer", "mv_workspace_bytes", "mv_hop", "mv_macs_per_frame", "mv_destroy", "mv_pcm16",
+    "mv_test_conv1d", "mv_test_conv_transpose1d",
+)
+
+
+class MelvocError(RuntimeError):
+    pass
+
+
+class mv_tensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.POINTER(C.c_float)), ("ndim", C.c_int), ("shape", C.c_int64 * 4)]
+
+
+class mv_hifigan_cfg(C.Structure):
+    _fields_ = [
+        ("num_mels", C.c_int),
+        ("upsample_initial_channel", C.c_int),
+        ("num_upsamples", C.c_int),
+        ("upsample_rates", C.c_int * 8),
+        ("upsample_kernel_sizes", C.c_int * 8),
+        ("num_kernels", C.c_int),
+        ("resblock_kernel_sizes", C.c_int * 8),
+        ("resblock_dilations", (C.c_int * 3) * 8),
+    ]
+
+
+class mv_waveglow_cfg(C.Structure):
+    _fields_ = [
+        ("n_mel_channels", C.c_int),
+        ("n_flows", C.c_int),
+        ("n_group", C.c_int),
+        ("n_early_every", C.c_int),
+        ("n_early_size", C.c_int),
+        ("n_layers", C.c_int),
+        ("n_channels", C.c_int),
+        ("kernel_size", C.c_int),
+    ]
+
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile libmelvoc.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    cmd = ["make", "-C", csrc, "-j8"] + (["-B"] if force else [])
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MelvocError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C tacotron2_amd/csrc`). There is no CPU fallback.")
+    l = C.CDLL(LIB_PATH)
+    vp, i32, f32p = C.c_void_p, C.c_int, C.POINTER(C.c_float)
+    l.mv_backend.restype = i32
+    l.mv_last_error.restype = C.c_char_p
+    l.mv_hifigan_create.argtypes = [C.POINTER(mv_hifigan_cfg), C.POINTER(mv_tensor), i32, i32, i32, C.POINTER(vp)]
+    l.mv_hifigan_forward.argtypes = [vp, vp, vp, i32, i32, vp, i32, vp, C.c_size_t, vp]
+    l.mv_waveglow_create.argtypes = [C.POINTER(mv_waveglow_cfg), C.POINTER(mv_tensor), i32, i32, i32, C.POINTER(vp)]
+    l.mv_waveglow_infer.argtypes = [vp, vp, vp, i32, i32, C.POINTER(vp), i32, C.c_float, vp, i32, vp, C.c_size_t, vp]
+    l.mv_workspace_bytes.argtypes = [vp, i32, i32]
+    l.mv_workspace_bytes.restype = C.c_size_t
+    l.mv_hop.argtypes = [vp]
+    l.mv_macs_per_frame.argtypes = [vp]
+    l.mv_macs_per_frame.restype = C.c_double
+    l.mv_destroy.argtypes = [vp]
+    l.mv_destroy.restype = None
+    l.mv_pcm16.argtypes = [vp, C.c_size_t, vp, vp]
+    l.mv_test_conv1d.argtypes = [vp, vp, i32, i32, i32, f32p, f32p, i32, i32, i32, C.c_float, i32, vp, vp]
+    l.mv_test_conv_transpose1d.argtypes = [vp, vp, i32, i32, i32, f32p, f32p, i32, i32, i32, i32, C.c_float, i32, vp, vp]
+    _lib = l
+    return l
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().mv_last_error().decode(errors="replace")
+        raise MelvocError(f"{what} failed (code {rc}): {msg}")
+
+
+def make_tensors(state):
+    """dict name -> float32 numpy array  =>  (ctypes array of mv_tensor, keep-alive list)."""
+    keep = []
+    arr = (mv_tensor * len(state))()
+    for i, (k, v) in enumerate(state.items()):
+        a = np.ascontiguousarray(np.asarray(v, dtype=np.float32))
+        if a.ndim < 1 or a.ndim > 4:
+            raise MelvocError(f"tensor {k}: unsupported rank {a.ndim}")
+        name = k.encode()
+        keep.append((a, name))
+        arr[i].name = name
+        arr[i].data = a.ctypes.data_as(C.POINTER(C.c_float))
+        arr[i].ndim = a.ndim
+        for d in range(a.ndim):
+            arr[i].shape[d] = a.shape[d]
+    return arr, keep
+
+
+def hifigan_cfg(cfg) -> mv_hifigan_cfg:
+    c = mv_hifigan_cfg()
+    c.num_mels = int(cfg.get("num_mels", 80))
+    c.upsample_initial_channel = int(cfg["upsample_initial_channel"])
+    rates, ks = list(cfg["upsample_rates"]), list(cfg["upsample_kernel_sizes"])
+    rk, rd = list(cfg["resblock_kernel_sizes"]), list(cfg["resblock_dilation_sizes"])
+    if len(rates) != len(ks) or len(rates) > 8 or len(rk) != len(rd) or len(rk) > 8:
+        raise MelvocError("hifigan config: inconsistent upsample / resblock lists")
+    c.num_upsamples = len(rates)
+    for i, (u, k) in enumerate(zip(rates, ks)):
+        c.upsample_rates[i] = int(u)
+        c.upsample_kernel_sizes[i] = int(k)
+    c.num_kernels = len(rk)
+    for j, (k, d) in enumerate(zip(rk, rd)):
+        if len(d) != 3:
+            raise MelvocError("hifigan config: ResBlock1 takes three dilations per kernel size")
+        c.resblock_kernel_sizes[j] = int(k)
+        for m in range(3):
+            c.resblock_dilations[j][m] = int(d[m])
+    return c
+
+
+def waveglow_cfg(cfg) -> mv_waveglow_cfg:
+    wn = cfg["WN_config"]
+    return mv_waveglow_cfg(int(cfg["n_mel_channels"]), int(cfg["n_flows"]), int(cfg["n_group"]),
+                           int(cfg["n_early_every"]), int(cfg["n_early_size"]), int(wn["n_layers"]),
+                           int(wn["n_channels"]), int(wn["kernel_size"]))
+
+
+class Handle:
+    """Owns an mv_handle; destroyed with the Python object."""
+
+    def __init__(self, ptr, kind):
+        self.ptr = C.c_void_p(ptr)
+        self.kind = kind
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().mv_destroy(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+    @property
+    def hop(self):
+        return lib().mv_hop(self.ptr)
+
+    @property
+    def macs_per_frame(self):
+        return lib().mv_macs_per_frame(self.ptr)
+
+    def workspace_bytes(self, B, Tmax):
+        return lib().mv_workspace_bytes(self.ptr, int(B), int(Tmax))
+
+
+def create_hifigan(cfg, state, device_index: int, precision: int) -> Handle:
+    arr, keep = make_tensors(state)
+    c = hifigan_cfg(cfg)
+    out = C.c_void_p()
+    check(lib().mv_hifigan_create(C.byref(c), arr, len(keep), int(device_index), int(precision), C.byref(out)),
+          "mv_hifigan_create")
+    return Handle(out.value, "hifigan")
+
+
+def create_waveglow(cfg, state, device_index: int, precision: int) -> Handle:
+    arr, keep = make_tensors(state)
+    c = waveglow_cfg(cfg)
+    out = C.c_void_p()
+    check(lib().mv_waveglow_create(C.byref(c), arr, len(keep), int(device_index), int(precision), C.byref(out)),
+          "mv_waveglow_create")
+    return Handle(out.value, "waveglow")

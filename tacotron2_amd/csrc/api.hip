@@ -1,0 +1,106 @@
+// api.hip -- handle-independent entry points of libmelvoc and the single-layer test hooks.
+#include "handle.h"
+
+namespace mv {
+const char* last_error_cstr();
+int build_conv1d_layer(Layer* L, const HostTensor* w, const HostTensor* b, int Cin, int Cout, int K, int dil,
+                       int cin_pad, int cout_pad, bool bf16, int force_cfg);
+int build_convT_layer(Layer* L, const HostTensor* w, const HostTensor* b, int Cin, int Cout, int K, int u, int cin_pad,
+                      int cout_pad, bool bf16, int force_cfg);
+int launch_convT(const Layer& L, const float* x, long long x_bs, int cin_stride, int rows_per_frame, float slope,
+                 float* y, long long y_bs, int cout_pad, int K, int u, int pad, const int32_t* lengths, int B,
+                 int Tmax, hipStream_t stream);
+}  // namespace mv
+
+using namespace mv;
+
+extern "C" {
+
+int mv_backend(void) { return 1; }
+
+const char* mv_last_error(void) { return last_error_cstr(); }
+
+size_t mv_workspace_bytes(mv_handle h, int B, int Tmax) {
+    if (!h || B < 1 || Tmax < 1) return 0;
+    return h->workspace_bytes(B, Tmax);
+}
+
+int mv_hop(mv_handle h) { return h ? h->hop() : 0; }
+
+double mv_macs_per_frame(mv_handle h) { return h ? h->macs_per_frame() : 0.0; }
+
+void mv_destroy(mv_handle h) {
+    if (!h) return;
+    DeviceGuard g(h->device);
+    delete h;
+}
+
+int mv_pcm16(const float* wav, size_t n, int16_t* pcm, void* stream) {
+    if (!wav || !pcm) {
+        set_error("mv_pcm16: null pointer");
+        return MV_EINVAL;
+    }
+    return launch_pcm16(wav, n, pcm, (hipStream_t)stream);
+}
+
+static int test_cfg() {
+    const char* s = getenv("MV_TEST_CFG");
+    return s && *s ? atoi(s) : -1;
+}
+
+int mv_test_conv1d(const float* x, const int32_t* lengths, int B, int L, int Cin, const float* w, const float* bias,
+                   int Cout, int K, int dilation, float pre_slope, int precision, float* y, void* stream) {
+    if (!x || !w || !y || B < 1 || L < 1 || Cin % 32 || Cout % 32 || K < 1 || K % 2 != 1 || dilation < 1) {
+        set_error("mv_test_conv1d: needs Cin, Cout multiples of 32 and an odd K");
+        return MV_EINVAL;
+    }
+    int rc = init_kernel_attributes();
+    if (rc) return rc;
+    HostTensor hw, hb;
+    hw.data.assign(w, w + (size_t)Cout * Cin * K);
+    if (bias) hb.data.assign(bias, bias + Cout);
+    Layer Lr;
+    rc = build_conv1d_layer(&Lr, &hw, bias ? &hb : nullptr, Cin, Cout, K, dilation, Cin, Cout, precision == MV_PREC_BF16,
+                            test_cfg());
+    if (rc) return rc;
+    SrcBind sb{x, (long long)L * Cin, Cin, 1, pre_slope};
+    LaunchArgs a;
+    a.lengths = lengths;
+    a.B = B;
+    a.Tmax = L;
+    a.out[0] = ConvOut{y, (long long)L * Cout, 0, Cout, Cout, ACC_STORE};
+    rc = launch_layer(Lr, &sb, 1, a, (hipStream_t)stream);
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    free_layer(&Lr);
+    if (rc) return rc;
+    MV_HIP(e);
+    return MV_OK;
+}
+
+int mv_test_conv_transpose1d(const float* x, const int32_t* lengths, int B, int L, int Cin, const float* w,
+                             const float* bias, int Cout, int K, int stride, int padding, float pre_slope,
+                             int precision, float* y, void* stream) {
+    if (!x || !w || !y || B < 1 || L < 1 || Cin % 32 || Cout % 32 || stride < 1 || K < stride ||
+        (K - stride) != 2 * padding) {
+        set_error("mv_test_conv_transpose1d: needs Cin, Cout multiples of 32 and K - stride == 2*padding");
+        return MV_EINVAL;
+    }
+    int rc = init_kernel_attributes();
+    if (rc) return rc;
+    HostTensor hw, hb;
+    hw.data.assign(w, w + (size_t)Cout * Cin * K);
+    if (bias) hb.data.assign(bias, bias + Cout);
+    Layer Lr;
+    rc = build_convT_layer(&Lr, &hw, bias ? &hb : nullptr, Cin, Cout, K, stride, Cin, Cout, precision == MV_PREC_BF16,
+                           test_cfg());
+    if (rc) return rc;
+    rc = launch_convT(Lr, x, (long long)L * Cin, Cin, 1, pre_slope, y, (long long)L * stride * Cout, Cout, K, stride,
+                      padding, lengths, B, L, (hipStream_t)stream);
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    free_layer(&Lr);
+    if (rc) return rc;
+    MV_HIP(e);
+    return MV_OK;
+}
+
+}  // extern "C"

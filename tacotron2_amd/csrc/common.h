@@ -1,0 +1,122 @@
+// common.h -- host-side plumbing shared by the libmelvoc translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/melvoc.h"
+#include "conv_mfma.h"
+
+namespace mv {
+
+void set_error(const char* fmt, ...);
+
+#define MV_HIP(call)                                                                           \
+    do {                                                                                       \
+        hipError_t _e = (call);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            mv::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return MV_EHIP;                                                                    \
+        }                                                                                      \
+    } while (0)
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// ---- kernel tile configurations -----------------------------------------------------------
+struct TileCfg {
+    int TM, TN, WM, WN;
+    int MT() const { return 16 * TM * WM; }
+    int NT() const { return 16 * TN * WN; }
+};
+extern const TileCfg kTileCfgs[];
+extern const int kNumTileCfgs;
+
+// A convolution repacked for conv_cl_kernel.
+struct LayerPass {
+    int src;  // index into the caller's source bindings
+    int cin_off, cb, ktaps, dil, pad_left;
+    int tap0;  // first tap of the source this pass covers (taps are split when the dilation exceeds the tile)
+};
+struct Layer {
+    void* w = nullptr;      // device, packed fragments
+    float* bias = nullptr;  // device [M]
+    int M = 0;
+    int steps_total = 0;
+    int npass = 0;
+    LayerPass pass[kMaxPass];
+    int cfg = 0;  // index into kTileCfgs
+    bool bf16 = false;
+    int epi = EPI_LINEAR;
+    size_t lds_bytes = 0;
+    double macs_per_n = 0;  // padded MACs per output row (diagnostics)
+};
+
+// One logical input of a layer: C channels (already padded to the k-chunk), taps, and the weight
+// as a function (m, tap, c) -> float in the *kernel's* tap order (input row = n + tap*dil - pad_left).
+struct SrcSpec {
+    int C;
+    int ktaps;
+    int dil;
+    int pad_left;
+    std::function<float(int, int, int)> w;
+};
+
+int build_layer(Layer* L, const std::vector<SrcSpec>& srcs, int M, const std::vector<float>& bias, bool bf16, int epi,
+                int force_cfg = -1);
+void free_layer(Layer* L);
+
+struct SrcBind {
+    const float* ptr;
+    long long batch_stride;
+    int row_stride;
+    int rows_per_frame;
+    float slope;
+};
+
+struct LaunchArgs {
+    const int32_t* lengths = nullptr;
+    int B = 1;
+    int Tmax = 0;
+    int n_rows_per_frame = 1;
+    int n_extra = 0;
+    int split = 1 << 30;
+    ConvOut out[2] = {};
+    const float* resid = nullptr;
+    long long resid_batch_stride = 0;
+    float div = 1.f;
+};
+
+int launch_layer(const Layer& L, const SrcBind* srcs, int nsrc, const LaunchArgs& a, hipStream_t stream);
+int init_kernel_attributes();
+
+// ---- weight lookup (state-dict names, weight-norm folding) --------------------------------
+struct HostTensor {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+    int64_t dim(int i) const { return i < (int)shape.size() ? shape[i] : 1; }
+};
+class WeightMap {
+   public:
+    int load(const mv_tensor* t, int n);
+    // folded weight ("name.weight" or g/v pair) or plain tensor; nullptr + error if missing
+    const HostTensor* get(const std::string& name);
+
+   private:
+    std::map<std::string, HostTensor> m_;
+};
+
+template <typename T>
+int upload(const std::vector<T>& host, T** dev) {
+    MV_HIP(hipMalloc((void**)dev, host.size() * sizeof(T)));
+    MV_HIP(hipMemcpy(*dev, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    return MV_OK;
+}
+
+}  // namespace mv

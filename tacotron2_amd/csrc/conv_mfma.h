@@ -1,0 +1,291 @@
+// conv_mfma.h -- the implicit-GEMM 1-D convolution kernel of libmelvoc (gfx950 only).
+//
+// One kernel covers every contraction of the two vocoders:
+//   Conv1d (any taps / dilation)           hifigan/models.py:99,101,150   waveglow/glow.py:164,168
+//   ConvTranspose1d as a polyphase conv    hifigan/models.py:153          waveglow/glow.py:252
+//   1x1 convs and the cond_layer slice fused as a second input            waveglow/glow.py:159,168
+//
+// GEMM view:  D[m][n] = sum_pass sum_tap sum_c  W[m][pass,tap,c] * X_pass[n + tap*dil - pad][c]
+//   M = output channels (for a transposed conv: phase-major  m = phase*Cout + co)
+//   N = time, K = taps x input channels.
+// Activations are float32, channels-last ([B][rows][C]) in HBM; a block stages the rows its
+// N-tile needs (halo included) into LDS, applying the consumer's leaky_relu and -- in bf16
+// mode -- the f32->bf16 rounding on the way, with rows outside [0, len) written as zeros:
+// that is the per-sequence zero padding of the reference's batch-1 call.  Weights are
+// pre-packed per 16-row M tile in MFMA A-fragment order and stream L2 -> registers.
+//
+// MFMA: bf16 mode  v_mfma_f32_16x16x32_bf16  (A,B: 8 bf16 per lane, k = 8*(lane>>4)+j)
+//       fp32 mode  v_mfma_f32_16x16x4_f32 x4 (A,B: 4 f32 per lane; MFMA j takes element j,
+//                  so both operands still load as one 16-byte vector per lane)
+//       C/D: col = lane&15 (time), row = 4*(lane>>4)+reg (output channel).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mv {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kMaxPass = 16;
+constexpr int kLdsRowPad = 32;  // bytes; row stride/16 == 2 (mod 4) makes ds_read_b128 conflict-free
+
+enum { EPI_LINEAR = 0, EPI_GATE = 1 };
+enum { ACC_STORE = 0, ACC_ADD = 1, ACC_ADD_DIV = 2 };
+
+struct ConvPass {
+    const float* src;        // channels-last f32 [B][rows][row_stride]
+    long long batch_stride;  // elements
+    int row_stride;          // elements
+    int cin_off;             // first channel staged by this pass
+    int cb;                  // channels staged (multiple of 32 in bf16 mode, 16 in fp32 mode)
+    int ktaps;
+    int dil;
+    int pad_left;            // input row of (n, tap) = n + tap*dil - pad_left
+    int rows_per_frame;      // valid input rows of sequence b = lengths[b] * rows_per_frame
+    float slope;             // leaky_relu slope applied while staging (1 = identity)
+};
+
+struct ConvOut {
+    float* ptr;
+    long long batch_stride;      // elements
+    long long off;               // element offset added to n*row_stride + m (may be negative)
+    long long valid_per_frame;   // elements e with 0 <= e < lengths[b]*valid_per_frame are written
+    int row_stride;              // elements per n
+    int mode;                    // ACC_*
+};
+
+struct ConvParams {
+    ConvPass pass[kMaxPass];
+    int npass;
+    const void* w;       // [M/16][steps_total][64 lanes][16 bytes]
+    int steps_total;
+    const float* bias;   // [M]
+    const int32_t* lengths;
+    int Tmax;            // frames
+    int n_rows_per_frame;
+    int n_extra;         // N extent of sequence b = lengths[b]*n_rows_per_frame + n_extra
+    int split;           // m >= split goes to out[1] with m -= split
+    ConvOut out[2];
+    const float* resid;  // optional, indexed like out[0]
+    long long resid_batch_stride;
+    float div;           // ACC_ADD_DIV divisor
+};
+
+template <bool BF16>
+__device__ __forceinline__ void mma16(f32x4& acc, const u32x4& a, const u32x4& b) {
+    if constexpr (BF16) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
+                                                      acc, 0, 0, 0);
+    } else {
+        const f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], bf[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1], bf[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[2], bf[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[3], bf[3], acc, 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ float lrelu(float x, float slope) { return x >= 0.f ? x : x * slope; }
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    bf16x2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, v);
+}
+
+// Stage rows [row0, row0+rows) x channels [cin_off, cin_off+cb) of one sequence into LDS.
+template <bool BF16, int NTHREADS>
+__device__ __forceinline__ void stage_tile(char* smem, const ConvPass& cp, const float* src_b, int row0, int rows,
+                                           int len_rows, int RS) {
+    constexpr int UC = BF16 ? 8 : 4;  // channels per 16-byte LDS unit
+    const int upr = cp.cb / UC;
+    const int total = rows * upr;
+    const float slope = cp.slope;
+    for (int idx = threadIdx.x; idx < total; idx += NTHREADS) {
+        const int r = idx / upr;
+        const int u = idx - r * upr;
+        const int in_row = row0 + r;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (in_row >= 0 && in_row < len_rows) {
+            const float* g = src_b + (long long)in_row * cp.row_stride + cp.cin_off + u * UC;
+            if constexpr (BF16) {
+                const f32x4 x0 = *(const f32x4*)g;
+                const f32x4 x1 = *(const f32x4*)(g + 4);
+                v[0] = pack_bf16(lrelu(x0[0], slope), lrelu(x0[1], slope));
+                v[1] = pack_bf16(lrelu(x0[2], slope), lrelu(x0[3], slope));
+                v[2] = pack_bf16(lrelu(x1[0], slope), lrelu(x1[1], slope));
+                v[3] = pack_bf16(lrelu(x1[2], slope), lrelu(x1[3], slope));
+            } else {
+                f32x4 x0 = *(const f32x4*)g;
+                x0[0] = lrelu(x0[0], slope);
+                x0[1] = lrelu(x0[1], slope);
+                x0[2] = lrelu(x0[2], slope);
+                x0[3] = lrelu(x0[3], slope);
+                v = __builtin_bit_cast(u32x4, x0);
+            }
+        }
+        *(u32x4*)(smem + r * RS + u * 16) = v;
+    }
+}
+
+// One pass of the K loop: S = ktaps * nkc steps; A fragments stream from global two steps ahead.
+template <bool BF16, int TM, int TN>
+__device__ __forceinline__ void mma_pass(f32x4 (&acc)[TM][TN], const char* lds_b, int RS, int ktaps, int dil, int nkc,
+                                         const u32x4* wlane, long long mtile_stride) {
+    const int S = ktaps * nkc;
+    const int tap_bytes = dil * RS;
+    u32x4 a0[TM], a1[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) a0[tm] = wlane[tm * mtile_stride];
+    if (S > 1) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) a1[tm] = wlane[tm * mtile_stride + 64];
+    }
+    int kc = 0;
+    const char* bp = lds_b;  // advances 64 B per k-chunk, wraps to the next tap
+    auto advance = [&]() {
+        ++kc;
+        bp += 64;
+        if (kc == nkc) {
+            kc = 0;
+            bp += tap_bytes - nkc * 64;
+        }
+    };
+    for (int s = 0; s < S; s += 2) {
+        {
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const u32x4 b = *(const u32x4*)(bp + tn * 16 * RS);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) mma16<BF16>(acc[tm][tn], a0[tm], b);
+            }
+            advance();
+            if (s + 2 < S) {
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) a0[tm] = wlane[tm * mtile_stride + (long long)(s + 2) * 64];
+            }
+        }
+        if (s + 1 < S) {
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const u32x4 b = *(const u32x4*)(bp + tn * 16 * RS);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) mma16<BF16>(acc[tm][tn], a1[tm], b);
+            }
+            advance();
+            if (s + 3 < S) {
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) a1[tm] = wlane[tm * mtile_stride + (long long)(s + 3) * 64];
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void store_out(const ConvOut& o, int b, long long e, long long valid, f32x4 v,
+                                          const float* resid_b, float div) {
+    if (e < 0 || e >= valid) return;
+    float* ptr = o.ptr + (long long)b * o.batch_stride + e;
+    if (resid_b) v += *(const f32x4*)(resid_b + e);
+    if (o.mode == ACC_ADD) {
+        v += *(const f32x4*)ptr;
+    } else if (o.mode == ACC_ADD_DIV) {
+        v += *(const f32x4*)ptr;
+        v[0] = v[0] / div;
+        v[1] = v[1] / div;
+        v[2] = v[2] / div;
+        v[3] = v[3] / div;
+    }
+    *(f32x4*)ptr = v;
+}
+
+template <bool BF16, int TM, int TN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(WM* WN * 64) void conv_cl_kernel(const ConvParams p) {
+    constexpr int MT = 16 * TM * WM, NT = 16 * TN * WN, NTHREADS = WM * WN * 64;
+    constexpr int ES = BF16 ? 2 : 4;
+    constexpr int CH = BF16 ? 32 : 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int b = blockIdx.z;
+    const int n0 = blockIdx.x * NT;
+    const int len = p.lengths ? p.lengths[b] : p.Tmax;
+    const int n_ext = len * p.n_rows_per_frame + p.n_extra;
+    if (n0 >= n_ext) return;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int lr = lane & 15, lg = lane >> 4;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int mtile0 = blockIdx.y * (MT / 16) + wm * TM;
+    const long long mtile_stride = (long long)p.steps_total * 64;
+    const u32x4* wlane = (const u32x4*)p.w + (long long)mtile0 * mtile_stride + lane;
+
+    int step_base = 0;
+    for (int ps = 0; ps < p.npass; ++ps) {
+        const ConvPass& cp = p.pass[ps];
+        const int rows = NT + (cp.ktaps - 1) * cp.dil;
+        const int RS = cp.cb * ES + kLdsRowPad;
+        if (ps > 0) __syncthreads();
+        stage_tile<BF16, NTHREADS>(smem, cp, cp.src + (long long)b * cp.batch_stride, n0 - cp.pad_left, rows,
+                                   len * cp.rows_per_frame, RS);
+        __syncthreads();
+        const int nkc = cp.cb / CH;
+        const char* lds_b = smem + (wn * TN * 16 + lr) * RS + lg * 16;
+        mma_pass<BF16, TM, TN>(acc, lds_b, RS, cp.ktaps, cp.dil, nkc, wlane + (long long)step_base * 64, mtile_stride);
+        step_base += cp.ktaps * nkc;
+    }
+
+    // ---- epilogue: lane holds 4 consecutive output channels of one time step per (tm, tn)
+    const float* resid_b = p.resid ? p.resid + (long long)b * p.resid_batch_stride : nullptr;
+    if constexpr (EPI == EPI_LINEAR) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            int m = (mtile0 + tm) * 16 + lg * 4;
+            const f32x4 bias = *(const f32x4*)(p.bias + m);
+            const int oi = m >= p.split ? 1 : 0;
+            const ConvOut& o = p.out[oi];
+            if (oi) m -= p.split;
+            const long long valid = (long long)len * o.valid_per_frame;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int n = n0 + (wn * TN + tn) * 16 + lr;
+                if (n >= n_ext) continue;
+                const long long e = (long long)n * o.row_stride + m + o.off;
+                store_out(o, b, e, valid, acc[tm][tn] + bias, oi ? nullptr : resid_b, p.div);
+            }
+        }
+    } else {
+        // gate (waveglow/glow.py:33-40): M tiles come in (tanh, sigmoid) pairs of the same 16 channels
+        static_assert(EPI != EPI_GATE || TM % 2 == 0, "gate epilogue needs tile pairs");
+        const ConvOut& o = p.out[0];
+        const long long valid = (long long)len * o.valid_per_frame;
+#pragma unroll
+        for (int tp = 0; tp < TM / 2; ++tp) {
+            const int mt = (mtile0 + 2 * tp) * 16 + lg * 4;
+            const f32x4 bt = *(const f32x4*)(p.bias + mt);
+            const f32x4 bs = *(const f32x4*)(p.bias + mt + 16);
+            const int ch = ((mtile0 >> 1) + tp) * 16 + lg * 4;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int n = n0 + (wn * TN + tn) * 16 + lr;
+                if (n >= n_ext) continue;
+                const f32x4 t = acc[2 * tp][tn] + bt;
+                const f32x4 s = acc[2 * tp + 1][tn] + bs;
+                f32x4 g;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[j] = tanhf(t[j]) * (1.0f / (1.0f + expf(-s[j])));
+                const long long e = (long long)n * o.row_stride + ch + o.off;
+                store_out(o, b, e, valid, g, nullptr, 1.f);
+            }
+        }
+    }
+}
+
+}  // namespace mv

@@ -1,0 +1,437 @@
+// hifigan.hip -- HiFi-GAN generator (hifigan/models.py:112-174 of the reference) on conv_cl_kernel.
+//
+// Data in HBM: every activation is float32, channels-last [B][rows][Cp] (Cp = channels rounded up
+// to 32, padding channels are exact zeros because their weights and biases are zero).
+// Launch sequence per forward (config_v1: 1 + 1 + 4*(1 + 3*3*2) + 1 = 79 launches):
+//   to_channels_last  mel [B][80][T] -> [B][T][96]
+//   conv_pre          models.py:150
+//   per stage i:      ups[i] as a polyphase conv with the leaky_relu(0.1) of models.py:152 applied
+//                     while staging; then for each ResBlock j and dilation m (models.py:96-103)
+//                       c1: lrelu -> dilated conv            -> T1
+//                       c2: lrelu -> conv, + residual        -> P / Q, the last one accumulates
+//                           the MRF mean (models.py:154-160) into ACC (store / add / add-then-divide,
+//                           the reference's own order of operations)
+//   conv_post         lrelu(0.01) -> Conv1d(C,1,7) -> tanh   (models.py:161-163), fp32 VALU
+#include <cmath>
+
+#include "handle.h"
+
+namespace mv {
+
+struct RbPair {
+    Layer c1, c2;
+};
+
+struct HifiganHandle : mv_handle_s {
+    mv_hifigan_cfg cfg;
+    int nstage = 0;
+    int C[9];   // channels entering stage i (C[0] = upsample_initial_channel) .. C[nstage]
+    int Cp[9];  // padded
+    int melp = 0;
+    Layer pre;
+    std::vector<Layer> ups;
+    std::vector<RbPair> rb;  // [(stage*num_kernels + j)*3 + m]
+    float* post_w = nullptr;  // device [7][Cp_last]
+    float* post_b = nullptr;  // device [1]
+    double macs = 0;
+
+    ~HifiganHandle() override {
+        free_layer(&pre);
+        for (auto& l : ups) free_layer(&l);
+        for (auto& p : rb) {
+            free_layer(&p.c1);
+            free_layer(&p.c2);
+        }
+        if (post_w) (void)hipFree(post_w);
+        if (post_b) (void)hipFree(post_b);
+    }
+    int hop() const override {
+        int h = 1;
+        for (int i = 0; i < nstage; ++i) h *= cfg.upsample_rates[i];
+        return h;
+    }
+    double macs_per_frame() const override { return macs; }
+    size_t stage_elems_per_frame() const {
+        size_t mx = 0, rows = 1;
+        for (int i = 0; i < nstage; ++i) {
+            rows *= cfg.upsample_rates[i];
+            mx = std::max(mx, rows * (size_t)Cp[i + 1]);
+        }
+        return mx;
+    }
+    static size_t al(size_t bytes) { return (bytes + 255) / 256 * 256; }
+    size_t workspace_bytes(int B, int Tmax) const override {
+        const size_t bt = (size_t)B * Tmax;
+        return al(bt * melp * 4) + al(bt * Cp[0] * 4) + 5 * al(bt * stage_elems_per_frame() * 4);
+    }
+};
+
+// ---- conv_post: lrelu(slope) -> Conv1d(C -> 1, k=7, pad=3) -> tanh -> f32 or PCM16 -----------
+template <bool PCM>
+__global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict__ x, long long batch_stride, int Cp,
+                                                        const float* __restrict__ w, const float* __restrict__ bias,
+                                                        const int32_t* __restrict__ lengths, int Tmax, int hop,
+                                                        float slope, void* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ws = (float*)smem;  // [7][Cp]
+    for (int i = threadIdx.x; i < 7 * Cp; i += 256) ws[i] = w[i];
+    __syncthreads();
+    const int b = blockIdx.y;
+    const long long L = (long long)Tmax * hop;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= L) return;
+    const long long len = (long long)(lengths ? lengths[b] : Tmax) * hop;
+    float y = 0.f;
+    if (t < len) {
+        const float* xb = x + (long long)b * batch_stride;
+        float acc = bias[0];
+        for (int k = 0; k < 7; ++k) {
+            const long long r = t + k - 3;
+            if (r < 0 || r >= len) continue;
+            const f32x4* xr = (const f32x4*)(xb + r * Cp);
+            const f32x4* wr = (const f32x4*)(ws + k * Cp);
+            for (int c = 0; c < Cp / 4; ++c) {
+                const f32x4 v = xr[c], q = wr[c];
+                acc += lrelu(v[0], slope) * q[0];
+                acc += lrelu(v[1], slope) * q[1];
+                acc += lrelu(v[2], slope) * q[2];
+                acc += lrelu(v[3], slope) * q[3];
+            }
+        }
+        y = tanhf(acc);
+    }
+    if constexpr (PCM)
+        ((int16_t*)out)[(long long)b * L + t] = (int16_t)(int32_t)(32768.0f * y);
+    else
+        ((float*)out)[(long long)b * L + t] = y;
+}
+
+static int conv_shape_check(const HostTensor* w, int64_t d0, int64_t d1, int64_t d2, const char* name) {
+    if (!w) return MV_ENOTFOUND;
+    if (w->shape.size() != 3 || w->shape[0] != d0 || w->shape[1] != d1 || w->shape[2] != d2) {
+        set_error("%s: expected shape [%lld,%lld,%lld]", name, (long long)d0, (long long)d1, (long long)d2);
+        return MV_EINVAL;
+    }
+    return MV_OK;
+}
+
+static int bias_check(const HostTensor* b, int64_t n, const char* name) {
+    if (!b) return MV_ENOTFOUND;
+    if ((int64_t)b->data.size() != n) {
+        set_error("%s: expected %lld entries", name, (long long)n);
+        return MV_EINVAL;
+    }
+    return MV_OK;
+}
+
+// Conv1d [Cout][Cin][K] as a layer; output/ input channels padded with zeros.
+int build_conv1d_layer(Layer* L, const HostTensor* w, const HostTensor* b, int Cin, int Cout, int K, int dil,
+                       int cin_pad, int cout_pad, bool bf16, int force_cfg = -1) {
+    const float* wd = w->data.data();
+    SrcSpec s;
+    s.C = cin_pad;
+    s.ktaps = K;
+    s.dil = dil;
+    s.pad_left = dil * (K - 1) / 2;
+    s.w = [=](int m, int tap, int c) -> float {
+        return (m < Cout && c < Cin) ? wd[((size_t)m * Cin + c) * K + tap] : 0.f;
+    };
+    std::vector<float> bias(cout_pad, 0.f);
+    for (int i = 0; i < Cout; ++i) bias[i] = b ? b->data[i] : 0.f;
+    return build_layer(L, {s}, cout_pad, bias, bf16, EPI_LINEAR, force_cfg);
+}
+
+// ConvTranspose1d [Cin][Cout][K], stride u, as a J-tap conv with M = u*cout_pad (phase-major).
+//   out[t = q*u + p - pad][co] = sum_j sum_ci x[q - j][ci] * w[ci][co][p + j*u]
+int build_convT_layer(Layer* L, const HostTensor* w, const HostTensor* b, int Cin, int Cout, int K, int u, int cin_pad,
+                      int cout_pad, bool bf16, int force_cfg = -1) {
+    const float* wd = w->data.data();
+    const int J = (K + u - 1) / u;
+    SrcSpec s;
+    s.C = cin_pad;
+    s.ktaps = J;
+    s.dil = 1;
+    s.pad_left = J - 1;
+    s.w = [=](int m, int tap, int c) -> float {
+        const int p = m / cout_pad, co = m - p * cout_pad;
+        const int k = p + (J - 1 - tap) * u;
+        return (co < Cout && c < Cin && k < K) ? wd[((size_t)c * Cout + co) * K + k] : 0.f;
+    };
+    std::vector<float> bias((size_t)u * cout_pad, 0.f);
+    for (int p = 0; p < u; ++p)
+        for (int i = 0; i < Cout; ++i) bias[(size_t)p * cout_pad + i] = b ? b->data[i] : 0.f;
+    return build_layer(L, {s}, u * cout_pad, bias, bf16, EPI_LINEAR, force_cfg);
+}
+
+// Launch a transposed-conv layer built by build_convT_layer.
+int launch_convT(const Layer& L, const float* x, long long x_bs, int cin_stride, int rows_per_frame, float slope,
+                 float* y, long long y_bs, int cout_pad, int K, int u, int pad, const int32_t* lengths, int B,
+                 int Tmax, hipStream_t stream) {
+    const int J = (K + u - 1) / u;
+    SrcBind sb{x, x_bs, cin_stride, rows_per_frame, slope};
+    LaunchArgs a;
+    a.lengths = lengths;
+    a.B = B;
+    a.Tmax = Tmax;
+    a.n_rows_per_frame = rows_per_frame;
+    a.n_extra = J - 1;
+    a.out[0].ptr = y;
+    a.out[0].batch_stride = y_bs;
+    a.out[0].row_stride = u * cout_pad;
+    a.out[0].off = -(long long)pad * cout_pad;
+    a.out[0].valid_per_frame = (long long)rows_per_frame * u * cout_pad;
+    a.out[0].mode = ACC_STORE;
+    return launch_layer(L, &sb, 1, a, stream);
+}
+
+static int hifigan_build(HifiganHandle* h, WeightMap& W) {
+    const mv_hifigan_cfg& c = h->cfg;
+    const bool bf16 = h->precision == MV_PREC_BF16;
+    char name[160];
+    int rc;
+    h->nstage = c.num_upsamples;
+    h->melp = round_up(c.num_mels, 32);
+    for (int i = 0; i <= h->nstage; ++i) {
+        h->C[i] = c.upsample_initial_channel >> i;
+        h->Cp[i] = round_up(h->C[i], 32);
+        if (h->C[i] < 1 || (h->C[i] << i) != c.upsample_initial_channel) {
+            set_error("upsample_initial_channel=%d is not divisible by 2^%d", c.upsample_initial_channel, i);
+            return MV_EINVAL;
+        }
+    }
+    double macs = 0;
+    {
+        const HostTensor* w = W.get("conv_pre.weight");
+        if ((rc = conv_shape_check(w, h->C[0], c.num_mels, 7, "conv_pre.weight"))) return rc;
+        const HostTensor* b = W.get("conv_pre.bias");
+        if ((rc = bias_check(b, h->C[0], "conv_pre.bias"))) return rc;
+        if ((rc = build_conv1d_layer(&h->pre, w, b, c.num_mels, h->C[0], 7, 1, h->melp, h->Cp[0], bf16))) return rc;
+        macs += (double)h->C[0] * c.num_mels * 7;
+    }
+    h->ups.resize(h->nstage);
+    h->rb.resize((size_t)h->nstage * c.num_kernels * 3);
+    double rows = 1;
+    for (int i = 0; i < h->nstage; ++i) {
+        const int u = c.upsample_rates[i], K = c.upsample_kernel_sizes[i];
+        if (u < 1 || K < u || (K - u) % 2 != 0) {
+            set_error("ups.%d: kernel %d / stride %d unsupported (needs K >= stride, K - stride even)", i, K, u);
+            return MV_EUNSUPPORTED;
+        }
+        snprintf(name, sizeof name, "ups.%d.weight", i);
+        const HostTensor* w = W.get(name);
+        if ((rc = conv_shape_check(w, h->C[i], h->C[i + 1], K, name))) return rc;
+        snprintf(name, sizeof name, "ups.%d.bias", i);
+        const HostTensor* b = W.get(name);
+        if ((rc = bias_check(b, h->C[i + 1], name))) return rc;
+        if ((rc = build_convT_layer(&h->ups[i], w, b, h->C[i], h->C[i + 1], K, u, h->Cp[i], h->Cp[i + 1], bf16)))
+            return rc;
+        macs += rows * (double)h->C[i] * h->C[i + 1] * K;  // every input row meets all K taps
+        rows *= u;
+        const int Cc = h->C[i + 1], Ccp = h->Cp[i + 1];
+        for (int j = 0; j < c.num_kernels; ++j) {
+            const int k = c.resblock_kernel_sizes[j];
+            if (k % 2 != 1) {
+                set_error("resblock kernel size %d must be odd", k);
+                return MV_EUNSUPPORTED;
+            }
+            for (int m = 0; m < 3; ++m) {
+                const int n = i * c.num_kernels + j;
+                RbPair& pr = h->rb[(size_t)n * 3 + m];
+                const int d = c.resblock_dilations[j][m];
+                for (int which = 0; which < 2; ++which) {
+                    snprintf(name, sizeof name, "resblocks.%d.convs%d.%d.weight", n, which + 1, m);
+                    const HostTensor* cw = W.get(name);
+                    if ((rc = conv_shape_check(cw, Cc, Cc, k, name))) return rc;
+                    snprintf(name, sizeof name, "resblocks.%d.convs%d.%d.bias", n, which + 1, m);
+                    const HostTensor* cb = W.get(name);
+                    if ((rc = bias_check(cb, Cc, name))) return rc;
+                    if ((rc = build_conv1d_layer(which ? &pr.c2 : &pr.c1, cw, cb, Cc, Cc, k, which ? 1 : d, Ccp, Ccp,
+                                                 bf16)))
+                        return rc;
+                    macs += rows * (double)Cc * Cc * k;
+                }
+            }
+        }
+    }
+    {
+        const int Cl = h->C[h->nstage], Clp = h->Cp[h->nstage];
+        const HostTensor* w = W.get("conv_post.weight");
+        if ((rc = conv_shape_check(w, 1, Cl, 7, "conv_post.weight"))) return rc;
+        const HostTensor* b = W.get("conv_post.bias");
+        if ((rc = bias_check(b, 1, "conv_post.bias"))) return rc;
+        std::vector<float> pw((size_t)7 * Clp, 0.f);
+        for (int cc = 0; cc < Cl; ++cc)
+            for (int k = 0; k < 7; ++k) pw[(size_t)k * Clp + cc] = w->data[(size_t)cc * 7 + k];
+        if ((rc = upload(pw, &h->post_w))) return rc;
+        if ((rc = upload(b->data, &h->post_b))) return rc;
+        macs += rows * (double)Cl * 7;
+    }
+    h->macs = macs;
+    return MV_OK;
+}
+
+static int hifigan_forward(HifiganHandle* h, const float* mel, const int32_t* lengths, int B, int Tmax, void* wav,
+                           int out_format, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    const mv_hifigan_cfg& c = h->cfg;
+    if (workspace_bytes < h->workspace_bytes(B, Tmax) || ((uintptr_t)workspace & 255) != 0) {
+        set_error("workspace: need %zu bytes, 256-byte aligned (got %zu)", h->workspace_bytes(B, Tmax),
+                  workspace_bytes);
+        return MV_ENOMEM;
+    }
+    int rc;
+    const size_t bt = (size_t)B * Tmax;
+    char* ws = (char*)workspace;
+    float* X0 = (float*)ws;
+    ws += HifiganHandle::al(bt * h->melp * 4);
+    float* PRE = (float*)ws;
+    ws += HifiganHandle::al(bt * h->Cp[0] * 4);
+    const size_t stage_bytes = HifiganHandle::al(bt * h->stage_elems_per_frame() * 4);
+    float* buf[5];
+    for (int i = 0; i < 5; ++i) buf[i] = (float*)(ws + i * stage_bytes);
+
+    if ((rc = launch_to_channels_last(mel, B, c.num_mels, Tmax, X0, h->melp, stream))) return rc;
+    {
+        SrcBind sb{X0, (long long)Tmax * h->melp, h->melp, 1, 1.0f};
+        LaunchArgs a;
+        a.lengths = lengths;
+        a.B = B;
+        a.Tmax = Tmax;
+        a.out[0] = ConvOut{PRE, (long long)Tmax * h->Cp[0], 0, h->Cp[0], h->Cp[0], ACC_STORE};
+        if ((rc = launch_layer(h->pre, &sb, 1, a, stream))) return rc;
+    }
+    const float* cur_in = PRE;  // input of the next upsampling
+    int rpf = 1;                // rows per mel frame of cur_in
+    int acc_idx = 1;            // buf[acc_idx] receives the MRF mean of this stage
+    for (int i = 0; i < h->nstage; ++i) {
+        const int u = c.upsample_rates[i], K = c.upsample_kernel_sizes[i];
+        const int Cin_p = h->Cp[i], Cp = h->Cp[i + 1];
+        const int rpf_out = rpf * u;
+        // buffers of this stage: A (ups output), ACC (MRF mean), T1, P, Q
+        float* A = buf[(acc_idx + 1) % 5];
+        float* ACC = buf[(acc_idx + 2) % 5];
+        float* T1 = buf[(acc_idx + 3) % 5];
+        float* PQ[2] = {buf[(acc_idx + 4) % 5], buf[acc_idx % 5]};  // the previous ACC is free once A is built
+        const long long bs_in = (long long)Tmax * rpf * Cin_p;
+        const long long bs = (long long)Tmax * rpf_out * Cp;
+        if ((rc = launch_convT(h->ups[i], cur_in, bs_in, Cin_p, rpf, 0.1f, A, bs, Cp, K, u, (K - u) / 2, lengths, B,
+                               Tmax, stream)))
+            return rc;
+        for (int j = 0; j < c.num_kernels; ++j) {
+            const float* cur = A;
+            for (int m = 0; m < 3; ++m) {
+                const RbPair& pr = h->rb[((size_t)i * c.num_kernels + j) * 3 + m];
+                LaunchArgs a;
+                a.lengths = lengths;
+                a.B = B;
+                a.Tmax = Tmax;
+                a.n_rows_per_frame = rpf_out;
+                a.out[0] = ConvOut{T1, bs, 0, (long long)rpf_out * Cp, Cp, ACC_STORE};
+                SrcBind s1{cur, bs, Cp, rpf_out, 0.1f};
+                if ((rc = launch_layer(pr.c1, &s1, 1, a, stream))) return rc;
+                SrcBind s2{T1, bs, Cp, rpf_out, 0.1f};
+                a.resid = cur;
+                a.resid_batch_stride = bs;
+                if (m < 2) {
+                    a.out[0].ptr = PQ[m];
+                } else {
+                    a.out[0].ptr = ACC;
+                    a.div = (float)c.num_kernels;
+                    a.out[0].mode = j == 0 ? ACC_STORE : (j == c.num_kernels - 1 ? ACC_ADD_DIV : ACC_ADD);
+                    if (c.num_kernels == 1) a.out[0].mode = ACC_STORE;
+                }
+                if ((rc = launch_layer(pr.c2, &s2, 1, a, stream))) return rc;
+                cur = PQ[m & 1];
+            }
+        }
+        cur_in = ACC;
+        rpf = rpf_out;
+        acc_idx = (acc_idx + 2) % 5;
+    }
+    {
+        const int Clp = h->Cp[h->nstage];
+        const long long L = (long long)Tmax * rpf;
+        dim3 grid((unsigned)((L + 255) / 256), (unsigned)B);
+        const size_t lds = (size_t)7 * Clp * 4;
+        if (out_format == MV_OUT_PCM16)
+            hipLaunchKernelGGL(conv_post_kernel<true>, grid, dim3(256), lds, stream, cur_in, L * Clp, Clp, h->post_w,
+                               h->post_b, lengths, Tmax, rpf, 0.01f, wav);
+        else
+            hipLaunchKernelGGL(conv_post_kernel<false>, grid, dim3(256), lds, stream, cur_in, L * Clp, Clp, h->post_w,
+                               h->post_b, lengths, Tmax, rpf, 0.01f, wav);
+        MV_HIP(hipGetLastError());
+    }
+    return MV_OK;
+}
+
+}  // namespace mv
+
+using namespace mv;
+
+extern "C" {
+
+int mv_hifigan_create(const mv_hifigan_cfg* cfg, const mv_tensor* weights, int n_weights, int device, int precision,
+                      mv_handle* out) {
+    if (!cfg || !weights || !out || n_weights <= 0) {
+        set_error("mv_hifigan_create: null argument");
+        return MV_EINVAL;
+    }
+    *out = nullptr;
+    if (precision != MV_PREC_FP32 && precision != MV_PREC_BF16) {
+        set_error("mv_hifigan_create: unknown precision %d", precision);
+        return MV_EINVAL;
+    }
+    if (cfg->num_upsamples < 1 || cfg->num_upsamples > 8 || cfg->num_kernels < 1 || cfg->num_kernels > 8 ||
+        cfg->num_mels < 1 || cfg->upsample_initial_channel < 1) {
+        set_error("mv_hifigan_create: bad config");
+        return MV_EINVAL;
+    }
+    DeviceGuard g(device);
+    if (!g.ok) {
+        set_error("mv_hifigan_create: cannot select HIP device %d", device);
+        return MV_EHIP;
+    }
+    int rc = init_kernel_attributes();
+    if (rc) return rc;
+    WeightMap W;
+    if ((rc = W.load(weights, n_weights))) return rc;
+    HifiganHandle* h = new HifiganHandle();
+    h->kind = 1;
+    h->device = device;
+    h->precision = precision;
+    h->cfg = *cfg;
+    if ((rc = hifigan_build(h, W))) {
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return MV_OK;
+}
+
+int mv_hifigan_forward(mv_handle hh, const float* mel, const int32_t* lengths, int B, int Tmax, void* wav,
+                       int out_format, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!hh || hh->kind != 1) {
+        set_error("mv_hifigan_forward: not a HiFi-GAN handle");
+        return MV_EINVAL;
+    }
+    if (!mel || !wav || !workspace || B < 1 || Tmax < 1) {
+        set_error("mv_hifigan_forward: bad argument (B=%d, Tmax=%d)", B, Tmax);
+        return MV_EINVAL;
+    }
+    if (out_format != MV_OUT_F32 && out_format != MV_OUT_PCM16) {
+        set_error("mv_hifigan_forward: unknown output format %d", out_format);
+        return MV_EINVAL;
+    }
+    if ((long long)Tmax * hh->hop() > (1LL << 30)) {
+        set_error("mv_hifigan_forward: Tmax too large");
+        return MV_EINVAL;
+    }
+    DeviceGuard g(hh->device);
+    if (!g.ok) {
+        set_error("mv_hifigan_forward: cannot select HIP device %d", hh->device);
+        return MV_EHIP;
+    }
+    return hifigan_forward(static_cast<HifiganHandle*>(hh), mel, lengths, B, Tmax, wav, out_format, workspace,
+                           workspace_bytes, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,301 @@
+// layers.hip -- weight repacking and launch of conv_cl_kernel (see conv_mfma.h).
+#include <cmath>
+#include <cstdlib>
+
+#include "common.h"
+
+namespace mv {
+
+static thread_local std::string g_err;
+
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+const char* last_error_cstr() { return g_err.c_str(); }
+
+//                              TM TN WM WN      MT   NT
+const TileCfg kTileCfgs[] = {
+    {4, 4, 4, 1},  // 0:  256 x  64
+    {4, 8, 4, 1},  // 1:  256 x 128
+    {4, 4, 2, 2},  // 2:  128 x 128
+    {4, 4, 1, 4},  // 3:   64 x 256
+    {2, 4, 1, 4},  // 4:   32 x 256
+    {2, 8, 1, 4},  // 5:   32 x 512
+    {4, 8, 1, 4},  // 6:   64 x 512
+    {4, 8, 2, 2},  // 7:  128 x 256
+};
+const int kNumTileCfgs = sizeof(kTileCfgs) / sizeof(kTileCfgs[0]);
+
+static int env_int(const char* name, int dflt) {
+    const char* s = getenv(name);
+    return s && *s ? atoi(s) : dflt;
+}
+
+static int default_cfg(int M) {
+    if (M % 256 == 0) return env_int("MV_CFG_M256", 1);
+    if (M % 128 == 0) return env_int("MV_CFG_M128", 2);
+    if (M % 64 == 0) return env_int("MV_CFG_M64", 3);
+    return env_int("MV_CFG_M32", 4);
+}
+
+static inline uint16_t f2bf(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+int build_layer(Layer* L, const std::vector<SrcSpec>& srcs, int M, const std::vector<float>& bias, bool bf16, int epi,
+                int force_cfg) {
+    const int CH = bf16 ? 32 : 16;
+    const int ES = bf16 ? 2 : 4;
+    if (M % 32 != 0 || (int)bias.size() != M) {
+        set_error("build_layer: M=%d must be a multiple of 32 with a bias of the same size", M);
+        return MV_EINVAL;
+    }
+    L->M = M;
+    L->bf16 = bf16;
+    L->epi = epi;
+    L->cfg = force_cfg >= 0 ? force_cfg : default_cfg(M);
+    const TileCfg& tc = kTileCfgs[L->cfg];
+    if (M % tc.MT() != 0 || (epi == EPI_GATE && tc.TM % 2 != 0)) {
+        set_error("build_layer: tile config %d does not fit M=%d", L->cfg, M);
+        return MV_EINVAL;
+    }
+    const size_t lds_budget = (size_t)env_int(bf16 ? "MV_LDS_BUDGET_KB" : "MV_LDS_BUDGET_KB_FP32", bf16 ? 64 : 128) * 1024;
+    L->npass = 0;
+    L->lds_bytes = 0;
+    L->steps_total = 0;
+    L->macs_per_n = 0;
+    for (size_t si = 0; si < srcs.size(); ++si) {
+        const SrcSpec& s = srcs[si];
+        if (s.C % CH != 0) {
+            set_error("build_layer: source %zu has %d channels, not a multiple of %d", si, s.C, CH);
+            return MV_EINVAL;
+        }
+        // taps further apart than half a tile share few rows: stage each tap on its own
+        const bool per_tap = s.ktaps > 1 && 2 * s.dil >= tc.NT();
+        const int groups = per_tap ? s.ktaps : 1;
+        const int gtaps = per_tap ? 1 : s.ktaps;
+        const int rows = tc.NT() + (gtaps - 1) * s.dil;
+        // split the channels until one staged tile fits the LDS budget (cb stays a multiple of CH)
+        int nsplit = 1;
+        while (true) {
+            const int cb = round_up((s.C + nsplit - 1) / nsplit, CH);
+            if ((size_t)rows * (cb * ES + kLdsRowPad) <= lds_budget || cb == CH) break;
+            ++nsplit;
+        }
+        const int cb0 = round_up((s.C + nsplit - 1) / nsplit, CH);
+        for (int g = 0; g < groups; ++g)
+            for (int off = 0; off < s.C; off += cb0) {
+                if (L->npass >= kMaxPass) {
+                    set_error("build_layer: more than %d passes needed", kMaxPass);
+                    return MV_EINVAL;
+                }
+                LayerPass& p = L->pass[L->npass++];
+                p.src = (int)si;
+                p.cin_off = off;
+                p.cb = std::min(cb0, s.C - off);
+                p.ktaps = gtaps;
+                p.dil = s.dil;
+                p.tap0 = g;
+                p.pad_left = s.pad_left - g * s.dil;
+                L->steps_total += p.ktaps * (p.cb / CH);
+                L->lds_bytes = std::max(L->lds_bytes, (size_t)rows * (p.cb * ES + kLdsRowPad));
+            }
+        L->macs_per_n += (double)M * s.C * s.ktaps;
+    }
+    if (L->lds_bytes > 160 * 1024) {
+        set_error("build_layer: needs %zu bytes of LDS", L->lds_bytes);
+        return MV_EINVAL;
+    }
+    // pack: [mtile][pass][tap][kc][lane][16 B]
+    const int mtiles = M / 16;
+    const size_t units = (size_t)mtiles * L->steps_total * 64;
+    std::vector<uint32_t> packed(units * 4);
+    const int per_lane = CH / 4;  // 8 bf16 or 4 f32
+    for (int mt = 0; mt < mtiles; ++mt) {
+        size_t step = 0;
+        for (int pi = 0; pi < L->npass; ++pi) {
+            const LayerPass& p = L->pass[pi];
+            const SrcSpec& s = srcs[p.src];
+            for (int tap = 0; tap < p.ktaps; ++tap)
+                for (int kc = 0; kc < p.cb / CH; ++kc, ++step)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int m = mt * 16 + (lane & 15);
+                        const int c0 = p.cin_off + kc * CH + (lane >> 4) * per_lane;
+                        uint32_t* dst = &packed[(((size_t)mt * L->steps_total + step) * 64 + lane) * 4];
+                        if (bf16) {
+                            for (int j = 0; j < 4; ++j) {
+                                const uint32_t lo = f2bf(s.w(m, p.tap0 + tap, c0 + 2 * j));
+                                const uint32_t hi = f2bf(s.w(m, p.tap0 + tap, c0 + 2 * j + 1));
+                                dst[j] = lo | (hi << 16);
+                            }
+                        } else {
+                            for (int j = 0; j < 4; ++j) {
+                                const float f = s.w(m, p.tap0 + tap, c0 + j);
+                                memcpy(&dst[j], &f, 4);
+                            }
+                        }
+                    }
+        }
+    }
+    uint32_t* dw = nullptr;
+    int rc = upload(packed, &dw);
+    if (rc) return rc;
+    L->w = dw;
+    return upload(bias, &L->bias);
+}
+
+void free_layer(Layer* L) {
+    if (L->w) (void)hipFree(L->w);
+    if (L->bias) (void)hipFree(L->bias);
+    L->w = nullptr;
+    L->bias = nullptr;
+}
+
+// ---- kernel table ---------------------------------------------------------------------------
+typedef void (*ConvKernel)(const ConvParams);
+
+template <bool BF16, int EPI>
+static ConvKernel kernel_for(int cfg) {
+    switch (cfg) {
+        case 0: return conv_cl_kernel<BF16, 4, 4, 4, 1, EPI>;
+        case 1: return conv_cl_kernel<BF16, 4, 8, 4, 1, EPI>;
+        case 2: return conv_cl_kernel<BF16, 4, 4, 2, 2, EPI>;
+        case 3: return conv_cl_kernel<BF16, 4, 4, 1, 4, EPI>;
+        case 4: return conv_cl_kernel<BF16, 2, 4, 1, 4, EPI>;
+        case 5: return conv_cl_kernel<BF16, 2, 8, 1, 4, EPI>;
+        case 6: return conv_cl_kernel<BF16, 4, 8, 1, 4, EPI>;
+        case 7: return conv_cl_kernel<BF16, 4, 8, 2, 2, EPI>;
+    }
+    return nullptr;
+}
+
+static ConvKernel pick_kernel(bool bf16, int epi, int cfg) {
+    if (bf16) return epi == EPI_GATE ? kernel_for<true, EPI_GATE>(cfg) : kernel_for<true, EPI_LINEAR>(cfg);
+    return epi == EPI_GATE ? kernel_for<false, EPI_GATE>(cfg) : kernel_for<false, EPI_LINEAR>(cfg);
+}
+
+int init_kernel_attributes() {
+    // per device: allow the full 160 KiB of dynamic LDS
+    for (int bf = 0; bf < 2; ++bf)
+        for (int epi = 0; epi < 2; ++epi)
+            for (int c = 0; c < kNumTileCfgs; ++c) {
+                ConvKernel k = pick_kernel(bf != 0, epi, c);
+                MV_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            }
+    return MV_OK;
+}
+
+int launch_layer(const Layer& L, const SrcBind* srcs, int nsrc, const LaunchArgs& a, hipStream_t stream) {
+    const TileCfg& tc = kTileCfgs[L.cfg];
+    ConvParams p;
+    memset(&p, 0, sizeof p);
+    p.npass = L.npass;
+    for (int i = 0; i < L.npass; ++i) {
+        const LayerPass& lp = L.pass[i];
+        if (lp.src >= nsrc) {
+            set_error("launch_layer: pass %d wants source %d of %d", i, lp.src, nsrc);
+            return MV_EINVAL;
+        }
+        const SrcBind& s = srcs[lp.src];
+        if (lp.cin_off + lp.cb > s.row_stride) {
+            set_error("launch_layer: source %d rows hold %d channels, pass needs %d", lp.src, s.row_stride,
+                      lp.cin_off + lp.cb);
+            return MV_EINVAL;
+        }
+        ConvPass& cp = p.pass[i];
+        cp.src = s.ptr;
+        cp.batch_stride = s.batch_stride;
+        cp.row_stride = s.row_stride;
+        cp.cin_off = lp.cin_off;
+        cp.cb = lp.cb;
+        cp.ktaps = lp.ktaps;
+        cp.dil = lp.dil;
+        cp.pad_left = lp.pad_left;
+        cp.rows_per_frame = s.rows_per_frame;
+        cp.slope = s.slope;
+    }
+    p.w = L.w;
+    p.steps_total = L.steps_total;
+    p.bias = L.bias;
+    p.lengths = a.lengths;
+    p.Tmax = a.Tmax;
+    p.n_rows_per_frame = a.n_rows_per_frame;
+    p.n_extra = a.n_extra;
+    p.split = a.split;
+    p.out[0] = a.out[0];
+    p.out[1] = a.out[1];
+    p.resid = a.resid;
+    p.resid_batch_stride = a.resid_batch_stride;
+    p.div = a.div;
+    const long long n_max = (long long)a.Tmax * a.n_rows_per_frame + a.n_extra;
+    if (n_max <= 0 || a.B <= 0) return MV_OK;
+    dim3 grid((unsigned)((n_max + tc.NT() - 1) / tc.NT()), (unsigned)(L.M / tc.MT()), (unsigned)a.B);
+    dim3 block(tc.WM * tc.WN * 64);
+    ConvKernel k = pick_kernel(L.bf16, L.epi, L.cfg);
+    hipLaunchKernelGGL(k, grid, block, L.lds_bytes, stream, p);
+    MV_HIP(hipGetLastError());
+    return MV_OK;
+}
+
+// ---- WeightMap ------------------------------------------------------------------------------
+int WeightMap::load(const mv_tensor* t, int n) {
+    for (int i = 0; i < n; ++i) {
+        if (!t[i].name || !t[i].data || t[i].ndim < 1 || t[i].ndim > 4) {
+            set_error("weights[%d]: bad tensor descriptor", i);
+            return MV_EINVAL;
+        }
+        HostTensor h;
+        size_t cnt = 1;
+        for (int d = 0; d < t[i].ndim; ++d) {
+            if (t[i].shape[d] <= 0) {
+                set_error("weights[%d] (%s): bad shape", i, t[i].name);
+                return MV_EINVAL;
+            }
+            h.shape.push_back(t[i].shape[d]);
+            cnt *= (size_t)t[i].shape[d];
+        }
+        h.data.assign(t[i].data, t[i].data + cnt);
+        m_[t[i].name] = std::move(h);
+    }
+    return MV_OK;
+}
+
+const HostTensor* WeightMap::get(const std::string& name) {
+    auto it = m_.find(name);
+    if (it != m_.end()) return &it->second;
+    const std::string suffix = ".weight";
+    if (name.size() > suffix.size() && name.compare(name.size() - suffix.size(), suffix.size(), suffix) == 0) {
+        auto g = m_.find(name + "_g"), v = m_.find(name + "_v");
+        if (g != m_.end() && v != m_.end()) {
+            // w = g * v / ||v||, norm over all dims but 0 (torch weight_norm, dim=0)
+            HostTensor w = v->second;
+            const size_t d0 = (size_t)w.shape[0];
+            const size_t inner = w.data.size() / d0;
+            if (g->second.data.size() != d0) {
+                set_error("%s_g has %zu entries, expected %zu", name.c_str(), g->second.data.size(), d0);
+                return nullptr;
+            }
+            for (size_t i = 0; i < d0; ++i) {
+                double ss = 0;
+                for (size_t j = 0; j < inner; ++j) ss += (double)w.data[i * inner + j] * w.data[i * inner + j];
+                const float scale = g->second.data[i] / (float)std::sqrt(ss);
+                for (size_t j = 0; j < inner; ++j) w.data[i * inner + j] *= scale;
+            }
+            auto ins = m_.emplace(name, std::move(w));
+            return &ins.first->second;
+        }
+    }
+    set_error("missing tensor '%s'", name.c_str());
+    return nullptr;
+}
+
+}  // namespace mv

@@ -1,0 +1,527 @@
+// waveglow.hip -- WaveGlow.infer (waveglow/glow.py:251-295 of the reference) on conv_cl_kernel.
+//
+// Data in HBM (float32, channels-last, L = 256*T/n_group time steps per sequence):
+//   SPECT [B][L][n_mel*n_group]  upsampled + regrouped mel (glow.py:252-260); the transposed conv
+//                                is a 4-tap polyphase conv whose M order is permuted so that its
+//                                natural output [frame][phase*80+mel] IS [l][mel*n_group+g]
+//   AUD   [B][L][n_group]        the flow state, right-aligned: the C_k live channels occupy
+//                                [n_group-C_k, n_group); prepending early-output noise (glow.py:287-292)
+//                                just lowers the start.  After flow 0 this buffer is the waveform
+//                                (sample = l*n_group + c, glow.py:294).
+//   H, SKIP, ACTS [B][L][C]      WN state (glow.py:153-175)
+// Per flow: start (VALU) -> n_layers x { in_layer + cond slice + gate (MFMA, EPI_GATE),
+// res_skip (MFMA, split epilogue: H += res, SKIP += skip) } -> tail (VALU: end 1x1, affine
+// coupling inverse, W^-1 1x1, early-output noise).  The cond_layer (glow.py:159) is never
+// materialised: each layer's 2C-slice of it is a second 1-tap input of that layer's GEMM.
+#include <cmath>
+
+#include "handle.h"
+
+namespace mv {
+
+struct WgFlow {
+    int Ck = 0, n_half = 0;
+    float* start_w = nullptr;  // device [C][n_half]
+    float* start_b = nullptr;  // device [C]
+    float* end_w = nullptr;    // device [2*n_half][Cp]
+    float* end_b = nullptr;    // device [2*n_half]
+    float* winv = nullptr;     // device [Ck][Ck]
+    std::vector<Layer> in_layers, res_skip;
+};
+
+struct WaveglowHandle : mv_handle_s {
+    mv_waveglow_cfg cfg;
+    int C = 0, Cp = 0, ncond = 0, melp = 0, n_rem = 0;
+    Layer up;
+    std::vector<WgFlow> flows;
+    double macs = 0;
+
+    ~WaveglowHandle() override {
+        free_layer(&up);
+        for (auto& f : flows) {
+            for (auto& l : f.in_layers) free_layer(&l);
+            for (auto& l : f.res_skip) free_layer(&l);
+            for (float* p : {f.start_w, f.start_b, f.end_w, f.end_b, f.winv})
+                if (p) (void)hipFree(p);
+        }
+    }
+    int hop() const override { return 256; }
+    double macs_per_frame() const override { return macs; }
+    static size_t al(size_t bytes) { return (bytes + 255) / 256 * 256; }
+    size_t workspace_bytes(int B, int Tmax) const override {
+        const size_t L = (size_t)Tmax * 256 / cfg.n_group;
+        const size_t bl = (size_t)B * L;
+        return al((size_t)B * Tmax * melp * 4) + al(bl * ncond * 4) + 3 * al(bl * Cp * 4) + al(bl * cfg.n_group * 4);
+    }
+};
+
+// AUD[b][l][off + c] = sigma * noise[b][c][l]
+__global__ __launch_bounds__(256) void wg_noise_kernel(const float* __restrict__ noise, int nc, int L, float sigma,
+                                                       float* __restrict__ aud, int ng, int off) {
+    const int b = blockIdx.y;
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= L) return;
+    for (int c = 0; c < nc; ++c) aud[((long long)b * L + l) * ng + off + c] = sigma * noise[((long long)b * nc + c) * L + l];
+}
+
+// glow.py:155: H = start(audio_0) (1x1, n_half -> C)
+__global__ __launch_bounds__(256) void wg_start_kernel(const float* __restrict__ aud, int ng, int off, int n_half,
+                                                       const float* __restrict__ w, const float* __restrict__ bias,
+                                                       int C, int Cp, long long rows, float* __restrict__ H) {
+    const int q = Cp / 4;  // float4 units per row
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * q) return;
+    const long long r = idx / q;
+    const int c0 = (int)(idx - r * q) * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    float a[4];
+    for (int j = 0; j < n_half; ++j) a[j] = aud[r * ng + off + j];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + i;
+        if (c < C) {
+            float s = 0.f;
+            for (int j = 0; j < n_half; ++j) s += w[c * n_half + j] * a[j];
+            v[i] = s + bias[c];
+        }
+    }
+    *(f32x4*)(H + r * Cp + c0) = v;
+}
+
+// glow.py:175 (end), 280-285 (coupling inverse, W^-1), 287-292 (early noise).  One wave per 16 steps:
+// lane = 16*part + step; the 4 parts split the channels of SKIP and are summed with two shuffles.
+__global__ __launch_bounds__(256) void wg_tail_kernel(const float* __restrict__ skip, int Cp, const float* __restrict__ end_w,
+                                                      const float* __restrict__ end_b, int n_half, int Ck,
+                                                      const float* __restrict__ winv, float* __restrict__ aud, int ng,
+                                                      const int32_t* __restrict__ lengths, int Tmax, int L,
+                                                      int steps_per_frame, const float* __restrict__ noise, int n_early,
+                                                      float sigma) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ws = (float*)smem;  // [2*n_half][Cp]
+    const int nout = 2 * n_half;
+    for (int i = threadIdx.x; i < nout * Cp; i += 256) ws[i] = end_w[i];
+    __syncthreads();
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int part = lane >> 4;
+    const int l = (blockIdx.x * 4 + wave) * 16 + (lane & 15);
+    const int len = (lengths ? lengths[b] : Tmax) * steps_per_frame;
+    const bool live = l < L;
+    const bool valid = live && l < len;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    if (valid) {
+        const f32x4* sr = (const f32x4*)(skip + ((long long)b * L + l) * Cp);
+        for (int c4 = part; c4 < Cp / 4; c4 += 4) {
+            const f32x4 v = sr[c4];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (j < nout) {
+                    const f32x4 q = *(const f32x4*)(ws + j * Cp + c4 * 4);
+                    acc[j] += v[0] * q[0] + v[1] * q[1] + v[2] * q[2] + v[3] * q[3];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        acc[j] += __shfl_xor(acc[j], 16);
+        acc[j] += __shfl_xor(acc[j], 32);
+    }
+    if (part != 0 || !live) return;
+    float* ar = aud + ((long long)b * L + l) * ng;
+    const int off = ng - Ck;
+    if (!valid) {
+        for (int c = 0; c < ng; ++c) ar[c] = 0.f;
+        return;
+    }
+    float a[8], o[8];
+    for (int c = 0; c < Ck; ++c) a[c] = ar[off + c];
+    for (int c = 0; c < n_half; ++c) {
+        const float bb = acc[c] + end_b[c];
+        const float s = acc[n_half + c] + end_b[n_half + c];
+        a[n_half + c] = (a[n_half + c] - bb) / expf(s);
+    }
+    for (int r = 0; r < Ck; ++r) {
+        float s = 0.f;
+        for (int c = 0; c < Ck; ++c) s += winv[r * Ck + c] * a[c];
+        o[r] = s;
+    }
+    for (int c = 0; c < Ck; ++c) ar[off + c] = o[c];
+    for (int j = 0; j < n_early; ++j) ar[off - n_early + j] = sigma * noise[((long long)b * n_early + j) * L + l];
+}
+
+static void invert_small(const float* A, int n, float* out) {
+    double a[8 * 16];
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            a[i * 2 * n + j] = A[i * n + j];
+            a[i * 2 * n + n + j] = i == j ? 1.0 : 0.0;
+        }
+    for (int c = 0; c < n; ++c) {
+        int p = c;
+        for (int r = c + 1; r < n; ++r)
+            if (std::fabs(a[r * 2 * n + c]) > std::fabs(a[p * 2 * n + c])) p = r;
+        if (p != c)
+            for (int j = 0; j < 2 * n; ++j) std::swap(a[c * 2 * n + j], a[p * 2 * n + j]);
+        const double d = a[c * 2 * n + c];
+        for (int j = 0; j < 2 * n; ++j) a[c * 2 * n + j] /= d;
+        for (int r = 0; r < n; ++r) {
+            if (r == c) continue;
+            const double f = a[r * 2 * n + c];
+            for (int j = 0; j < 2 * n; ++j) a[r * 2 * n + j] -= f * a[c * 2 * n + j];
+        }
+    }
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) out[i * n + j] = (float)a[i * 2 * n + n + j];
+}
+
+static int expect(const HostTensor* t, std::initializer_list<int64_t> shape, const char* name) {
+    if (!t) return MV_ENOTFOUND;
+    size_t i = 0;
+    bool ok = t->shape.size() >= shape.size();
+    for (int64_t d : shape) ok = ok && i < t->shape.size() && t->shape[i++] == d;
+    for (; i < t->shape.size(); ++i) ok = ok && t->shape[i] == 1;
+    if (!ok) {
+        set_error("%s: unexpected shape", name);
+        return MV_EINVAL;
+    }
+    return MV_OK;
+}
+
+static int waveglow_build(WaveglowHandle* h, WeightMap& W) {
+    const mv_waveglow_cfg& c = h->cfg;
+    const bool bf16 = h->precision == MV_PREC_BF16;
+    const int C = c.n_channels, nl = c.n_layers, ks = c.kernel_size, ng = c.n_group, nm = c.n_mel_channels;
+    h->C = C;
+    h->Cp = round_up(C, 32);
+    h->ncond = nm * ng;
+    h->melp = round_up(nm, 32);
+    if (C % 32 != 0 || h->ncond % 32 != 0 || ks % 2 != 1 || ng > 8 || ng % 2 != 0 || 256 % ng != 0) {
+        set_error("waveglow: unsupported shape (n_channels=%d, n_group=%d, kernel_size=%d)", C, ng, ks);
+        return MV_EUNSUPPORTED;
+    }
+    char name[160];
+    int rc;
+    double macs_step = 0;
+    {
+        // glow.py:183-185,252-260: ConvTranspose1d(nm, nm, 1024, stride 256) + trim + regroup
+        const int K = 1024, u = 256, J = 4;
+        const HostTensor* w = W.get("upsample.weight");
+        if ((rc = expect(w, {nm, nm, K}, "upsample.weight"))) return rc;
+        const HostTensor* b = W.get("upsample.bias");
+        if ((rc = expect(b, {nm}, "upsample.bias"))) return rc;
+        const float* wd = w->data.data();
+        const int per_row = nm * ng;  // channels of one SPECT row
+        SrcSpec s;
+        s.C = h->melp;
+        s.ktaps = J;
+        s.dil = 1;
+        s.pad_left = J - 1;
+        // m = (p / ng) * per_row + mel * ng + (p % ng), p = phase of the stride-256 transposed conv
+        s.w = [=](int m, int tap, int ci) -> float {
+            const int row = m / per_row, rem = m - row * per_row;
+            const int mel = rem / ng, g = rem - mel * ng;
+            const int p = row * ng + g;
+            const int k = p + (J - 1 - tap) * u;
+            return ci < nm ? wd[((size_t)ci * nm + mel) * K + k] : 0.f;
+        };
+        const int M = u * nm;
+        std::vector<float> bias(M);
+        for (int m = 0; m < M; ++m) bias[m] = b->data[(m % per_row) / ng];
+        // always exact fp32: 0.08 % of the FLOPs, and it feeds every flow
+        if ((rc = build_layer(&h->up, {s}, M, bias, false, EPI_LINEAR))) return rc;
+    }
+    h->flows.resize(c.n_flows);
+    int n_half = ng / 2, n_rem = ng;
+    for (int k = 0; k < c.n_flows; ++k) {
+        if (k % c.n_early_every == 0 && k > 0) {
+            n_half -= c.n_early_size / 2;
+            n_rem -= c.n_early_size;
+        }
+        if (n_half < 1 || n_rem != 2 * n_half) {
+            set_error("waveglow: flow %d has %d channels / n_half %d", k, n_rem, n_half);
+            return MV_EUNSUPPORTED;
+        }
+        WgFlow& f = h->flows[k];
+        f.Ck = n_rem;
+        f.n_half = n_half;
+        snprintf(name, sizeof name, "convinv.%d.conv.weight", k);
+        const HostTensor* wi = W.get(name);
+        if ((rc = expect(wi, {n_rem, n_rem}, name))) return rc;
+        std::vector<float> inv((size_t)n_rem * n_rem);
+        invert_small(wi->data.data(), n_rem, inv.data());
+        if ((rc = upload(inv, &f.winv))) return rc;
+
+        snprintf(name, sizeof name, "WN.%d.start.weight", k);
+        const HostTensor* sw = W.get(name);
+        if ((rc = expect(sw, {C, n_half}, name))) return rc;
+        snprintf(name, sizeof name, "WN.%d.start.bias", k);
+        const HostTensor* sbias = W.get(name);
+        if ((rc = expect(sbias, {C}, name))) return rc;
+        if ((rc = upload(sw->data, &f.start_w)) || (rc = upload(sbias->data, &f.start_b))) return rc;
+
+        snprintf(name, sizeof name, "WN.%d.end.weight", k);
+        const HostTensor* ew = W.get(name);
+        if ((rc = expect(ew, {2 * n_half, C}, name))) return rc;
+        snprintf(name, sizeof name, "WN.%d.end.bias", k);
+        const HostTensor* eb = W.get(name);
+        if ((rc = expect(eb, {2 * n_half}, name))) return rc;
+        std::vector<float> ewp((size_t)2 * n_half * h->Cp, 0.f);
+        for (int j = 0; j < 2 * n_half; ++j)
+            for (int cc = 0; cc < C; ++cc) ewp[(size_t)j * h->Cp + cc] = ew->data[(size_t)j * C + cc];
+        if ((rc = upload(ewp, &f.end_w)) || (rc = upload(eb->data, &f.end_b))) return rc;
+
+        snprintf(name, sizeof name, "WN.%d.cond_layer.weight", k);
+        const HostTensor* cw = W.get(name);
+        if ((rc = expect(cw, {2 * C * nl, h->ncond}, name))) return rc;
+        snprintf(name, sizeof name, "WN.%d.cond_layer.bias", k);
+        const HostTensor* cb = W.get(name);
+        if ((rc = expect(cb, {2 * C * nl}, name))) return rc;
+
+        f.in_layers.resize(nl);
+        f.res_skip.resize(nl);
+        for (int i = 0; i < nl; ++i) {
+            snprintf(name, sizeof name, "WN.%d.in_layers.%d.weight", k, i);
+            const HostTensor* iw = W.get(name);
+            if ((rc = expect(iw, {2 * C, C, ks}, name))) return rc;
+            snprintf(name, sizeof name, "WN.%d.in_layers.%d.bias", k, i);
+            const HostTensor* ib = W.get(name);
+            if ((rc = expect(ib, {2 * C}, name))) return rc;
+            const float* iwd = iw->data.data();
+            const float* cwd = cw->data.data() + (size_t)i * 2 * C * h->ncond;
+            const float* cbd = cb->data.data() + (size_t)i * 2 * C;
+            // M tiles in (tanh, sigmoid) pairs: tile 2j -> channels 16j.., tile 2j+1 -> C + 16j..
+            auto orig = [=](int m) {
+                const int tile = m >> 4, r = m & 15;
+                return ((tile & 1) ? C : 0) + (tile >> 1) * 16 + r;
+            };
+            const int d = 1 << i;
+            SrcSpec sh;
+            sh.C = h->Cp;
+            sh.ktaps = ks;
+            sh.dil = d;
+            sh.pad_left = d * (ks - 1) / 2;
+            sh.w = [=](int m, int tap, int ci) -> float {
+                return ci < C ? iwd[((size_t)orig(m) * C + ci) * ks + tap] : 0.f;
+            };
+            SrcSpec sc;
+            sc.C = h->ncond;
+            sc.ktaps = 1;
+            sc.dil = 1;
+            sc.pad_left = 0;
+            const int ncond = h->ncond;
+            sc.w = [=](int m, int, int ci) -> float { return cwd[(size_t)orig(m) * ncond + ci]; };
+            std::vector<float> bias(2 * C);
+            for (int m = 0; m < 2 * C; ++m) bias[m] = ib->data[orig(m)] + cbd[orig(m)];
+            if ((rc = build_layer(&f.in_layers[i], {sh, sc}, 2 * C, bias, bf16, EPI_GATE))) return rc;
+
+            const int rsC = i < nl - 1 ? 2 * C : C;
+            snprintf(name, sizeof name, "WN.%d.res_skip_layers.%d.weight", k, i);
+            const HostTensor* rw = W.get(name);
+            if ((rc = expect(rw, {rsC, C}, name))) return rc;
+            snprintf(name, sizeof name, "WN.%d.res_skip_layers.%d.bias", k, i);
+            const HostTensor* rb = W.get(name);
+            if ((rc = expect(rb, {rsC}, name))) return rc;
+            const float* rwd = rw->data.data();
+            SrcSpec sa;
+            sa.C = h->Cp;
+            sa.ktaps = 1;
+            sa.dil = 1;
+            sa.pad_left = 0;
+            sa.w = [=](int m, int, int ci) -> float { return ci < C ? rwd[(size_t)m * C + ci] : 0.f; };
+            if ((rc = build_layer(&f.res_skip[i], {sa}, rsC, rb->data, bf16, EPI_LINEAR))) return rc;
+        }
+        macs_step += (double)n_half * C + (double)h->ncond * 2 * C * nl + (double)nl * 2 * C * C * ks +
+                     ((double)(nl - 1) * 2 * C * C + (double)C * C) + (double)C * 2 * n_half + (double)n_rem * n_rem;
+    }
+    h->n_rem = n_rem;
+    h->macs = macs_step * (256 / ng) + (double)nm * nm * 1024;
+    return MV_OK;
+}
+
+static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* lengths, int B, int Tmax,
+                          const float* const* noise, int n_noise, float sigma, void* wav, int out_format,
+                          void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    const mv_waveglow_cfg& c = h->cfg;
+    const int ng = c.n_group, nl = c.n_layers, Cp = h->Cp;
+    const int spf = 256 / ng;  // time steps per mel frame
+    const int L = Tmax * spf;
+    if (workspace_bytes < h->workspace_bytes(B, Tmax) || ((uintptr_t)workspace & 255) != 0) {
+        set_error("workspace: need %zu bytes, 256-byte aligned (got %zu)", h->workspace_bytes(B, Tmax),
+                  workspace_bytes);
+        return MV_ENOMEM;
+    }
+    int n_early_flows = 0;
+    for (int k = 0; k < c.n_flows; ++k)
+        if (k % c.n_early_every == 0 && k > 0) ++n_early_flows;
+    if (n_noise != 1 + n_early_flows) {
+        set_error("mv_waveglow_infer: expected %d noise tensors, got %d", 1 + n_early_flows, n_noise);
+        return MV_EINVAL;
+    }
+    for (int i = 0; i < n_noise; ++i)
+        if (!noise[i]) {
+            set_error("mv_waveglow_infer: noise[%d] is null", i);
+            return MV_EINVAL;
+        }
+    int rc;
+    const size_t bl = (size_t)B * L;
+    char* ws = (char*)workspace;
+    float* X0 = (float*)ws;
+    ws += WaveglowHandle::al((size_t)B * Tmax * h->melp * 4);
+    float* SPECT = (float*)ws;
+    ws += WaveglowHandle::al(bl * h->ncond * 4);
+    float* H = (float*)ws;
+    ws += WaveglowHandle::al(bl * Cp * 4);
+    float* SKIP = (float*)ws;
+    ws += WaveglowHandle::al(bl * Cp * 4);
+    float* ACTS = (float*)ws;
+    ws += WaveglowHandle::al(bl * Cp * 4);
+    float* AUDW = (float*)ws;
+    // float output: the flow state lives directly in the caller's wav buffer
+    float* AUD = out_format == MV_OUT_F32 ? (float*)wav : AUDW;
+
+    if ((rc = launch_to_channels_last(mel, B, c.n_mel_channels, Tmax, X0, h->melp, stream))) return rc;
+    {
+        SrcBind sb{X0, (long long)Tmax * h->melp, h->melp, 1, 1.0f};
+        LaunchArgs a;
+        a.lengths = lengths;
+        a.B = B;
+        a.Tmax = Tmax;
+        a.n_rows_per_frame = 1;
+        a.n_extra = 3;
+        const long long per_frame = (long long)spf * h->ncond;  // = 256 * n_mel
+        a.out[0] = ConvOut{SPECT, (long long)Tmax * per_frame, 0, per_frame, (int)per_frame, ACC_STORE};
+        if ((rc = launch_layer(h->up, &sb, 1, a, stream))) return rc;
+    }
+    {
+        dim3 grid((L + 255) / 256, B);
+        hipLaunchKernelGGL(wg_noise_kernel, grid, dim3(256), 0, stream, noise[0], h->n_rem, L, sigma, AUD, ng,
+                           ng - h->n_rem);
+        MV_HIP(hipGetLastError());
+    }
+    int ni = 1;
+    const long long bsC = (long long)L * Cp;
+    for (int k = c.n_flows - 1; k >= 0; --k) {
+        const WgFlow& f = h->flows[k];
+        {
+            const long long rows = (long long)B * L;
+            const long long total = rows * (Cp / 4);
+            hipLaunchKernelGGL(wg_start_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, AUD, ng,
+                               ng - f.Ck, f.n_half, f.start_w, f.start_b, h->C, Cp, rows, H);
+            MV_HIP(hipGetLastError());
+        }
+        for (int i = 0; i < nl; ++i) {
+            SrcBind sb[2] = {{H, bsC, Cp, spf, 1.0f}, {SPECT, (long long)L * h->ncond, h->ncond, spf, 1.0f}};
+            LaunchArgs a;
+            a.lengths = lengths;
+            a.B = B;
+            a.Tmax = Tmax;
+            a.n_rows_per_frame = spf;
+            a.out[0] = ConvOut{ACTS, bsC, 0, (long long)spf * Cp, Cp, ACC_STORE};
+            if ((rc = launch_layer(f.in_layers[i], sb, 2, a, stream))) return rc;
+            SrcBind sa{ACTS, bsC, Cp, spf, 1.0f};
+            LaunchArgs r;
+            r.lengths = lengths;
+            r.B = B;
+            r.Tmax = Tmax;
+            r.n_rows_per_frame = spf;
+            const int skip_mode = i == 0 ? ACC_STORE : ACC_ADD;
+            if (i < nl - 1) {
+                r.split = h->C;
+                r.out[0] = ConvOut{H, bsC, 0, (long long)spf * Cp, Cp, ACC_ADD};
+                r.out[1] = ConvOut{SKIP, bsC, 0, (long long)spf * Cp, Cp, skip_mode};
+            } else {
+                r.out[0] = ConvOut{SKIP, bsC, 0, (long long)spf * Cp, Cp, skip_mode};
+            }
+            if ((rc = launch_layer(f.res_skip[i], &sa, 1, r, stream))) return rc;
+        }
+        const bool early = k % c.n_early_every == 0 && k > 0;
+        {
+            dim3 grid((L + 63) / 64, B);
+            const size_t lds = (size_t)2 * f.n_half * Cp * 4;
+            hipLaunchKernelGGL(wg_tail_kernel, grid, dim3(256), lds, stream, SKIP, Cp, f.end_w, f.end_b, f.n_half, f.Ck,
+                               f.winv, AUD, ng, lengths, Tmax, L, spf, early ? noise[ni] : nullptr,
+                               early ? c.n_early_size : 0, sigma);
+            MV_HIP(hipGetLastError());
+        }
+        if (early) ++ni;
+    }
+    if (out_format == MV_OUT_PCM16) return launch_pcm16(AUD, bl * ng, (int16_t*)wav, stream);
+    return MV_OK;
+}
+
+}  // namespace mv
+
+using namespace mv;
+
+extern "C" {
+
+int mv_waveglow_create(const mv_waveglow_cfg* cfg, const mv_tensor* weights, int n_weights, int device, int precision,
+                       mv_handle* out) {
+    if (!cfg || !weights || !out || n_weights <= 0) {
+        set_error("mv_waveglow_create: null argument");
+        return MV_EINVAL;
+    }
+    *out = nullptr;
+    if (precision != MV_PREC_FP32 && precision != MV_PREC_BF16) {
+        set_error("mv_waveglow_create: unknown precision %d", precision);
+        return MV_EINVAL;
+    }
+    if (cfg->n_flows < 1 || cfg->n_flows > 64 || cfg->n_layers < 1 || cfg->n_layers > 16 || cfg->n_early_every < 1 ||
+        cfg->n_early_size < 0 || cfg->n_early_size % 2 != 0 || cfg->n_mel_channels < 1) {
+        set_error("mv_waveglow_create: bad config");
+        return MV_EINVAL;
+    }
+    DeviceGuard g(device);
+    if (!g.ok) {
+        set_error("mv_waveglow_create: cannot select HIP device %d", device);
+        return MV_EHIP;
+    }
+    int rc = init_kernel_attributes();
+    if (rc) return rc;
+    WeightMap W;
+    if ((rc = W.load(weights, n_weights))) return rc;
+    WaveglowHandle* h = new WaveglowHandle();
+    h->kind = 2;
+    h->device = device;
+    h->precision = precision;
+    h->cfg = *cfg;
+    if ((rc = waveglow_build(h, W))) {
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return MV_OK;
+}
+
+int mv_waveglow_infer(mv_handle hh, const float* mel, const int32_t* lengths, int B, int Tmax,
+                      const float* const* noise, int n_noise, float sigma, void* wav, int out_format, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+    if (!hh || hh->kind != 2) {
+        set_error("mv_waveglow_infer: not a WaveGlow handle");
+        return MV_EINVAL;
+    }
+    if (!mel || !wav || !workspace || !noise || B < 1 || Tmax < 1) {
+        set_error("mv_waveglow_infer: bad argument (B=%d, Tmax=%d)", B, Tmax);
+        return MV_EINVAL;
+    }
+    if (out_format != MV_OUT_F32 && out_format != MV_OUT_PCM16) {
+        set_error("mv_waveglow_infer: unknown output format %d", out_format);
+        return MV_EINVAL;
+    }
+    if ((long long)Tmax * 256 > (1LL << 30)) {
+        set_error("mv_waveglow_infer: Tmax too large");
+        return MV_EINVAL;
+    }
+    DeviceGuard g(hh->device);
+    if (!g.ok) {
+        set_error("mv_waveglow_infer: cannot select HIP device %d", hh->device);
+        return MV_EHIP;
+    }
+    return waveglow_infer(static_cast<WaveglowHandle*>(hh), mel, lengths, B, Tmax, noise, n_noise, sigma, wav,
+                          out_format, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+}  // extern "C"

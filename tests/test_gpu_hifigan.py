@@ -1,0 +1,130 @@
+"""GPU parity of the native HiFi-GAN generator (tacotron2_amd.hifigan.Generator -> libmelvoc.so)
+against golden vectors captured from the reference Generator and against the C oracle.
+Bars (BASELINE.json): fp32 max-abs <= 1e-3; bf16 SNR >= 40 dB."""
+import copy
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import c_oracle  # noqa: E402
+from tacotron2_amd import synth  # noqa: E402
+from tacotron2_amd.hifigan import AttrDict, Generator  # noqa: E402
+
+
+def _snr(ref, x):
+    ref = np.asarray(ref, np.float64)
+    return 10 * np.log10((ref ** 2).sum() / max(((ref - np.asarray(x, np.float64)) ** 2).sum(), 1e-300))
+
+
+def _gen(cfg, seed, precision, weight_norm=True):
+    g = Generator(AttrDict(cfg), precision=precision)
+    sd = synth.hifigan_state(cfg, seed, weight_norm=weight_norm)
+    g.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    g.eval()
+    g.remove_weight_norm()
+    return g.to("cuda")
+
+
+@pytest.fixture(scope="module")
+def gen_fp32():
+    return _gen(synth.HIFIGAN_V1, 0, "fp32")
+
+
+@pytest.fixture(scope="module")
+def gen_bf16():
+    return _gen(synth.HIFIGAN_V1, 0, "bf16")
+
+
+def test_v1_T64_fp32_golden(golden_dir, gen_fp32):
+    d = np.load(os.path.join(golden_dir, "hifigan_v1_T64.npz"))
+    mel = torch.from_numpy(synth.synthetic_mel(64, int(d["mel_seed"]))).cuda()
+    y3 = gen_fp32(mel[None])
+    assert y3.shape == (1, 1, 64 * 256) and y3.dtype == torch.float32
+    assert np.abs(y3[0, 0].cpu().numpy() - d["wav"]).max() <= 1e-3
+    # do_syn.py:391 passes the 2-D mel: [80,T] -> [1,256T], same values
+    y2 = gen_fp32(mel)
+    assert y2.shape == (1, 64 * 256)
+    assert torch.equal(y2, y3[0])
+
+
+def test_v1_T500_fp32_golden(golden_dir, gen_fp32):
+    d = np.load(os.path.join(golden_dir, "hifigan_v1_T500.npz"))
+    mel = torch.from_numpy(synth.synthetic_mel(500, int(d["mel_seed"]))).cuda()
+    y = gen_fp32(mel[None])[0, 0].cpu().numpy()
+    err = np.abs(y - d["wav"]).max()
+    assert err <= 1e-3, err
+
+
+def test_v1_bf16_snr(golden_dir, gen_bf16):
+    for name, T in (("hifigan_v1_T64", 64), ("hifigan_v1_T500", 500)):
+        d = np.load(os.path.join(golden_dir, name + ".npz"))
+        mel = torch.from_numpy(synth.synthetic_mel(T, int(d["mel_seed"]))).cuda()
+        y = gen_bf16(mel[None])[0, 0].cpu().numpy()
+        assert _snr(d["wav"], y) >= 40.0, (name, _snr(d["wav"], y))
+
+
+def test_ragged_batch_equals_batch1(golden_dir, gen_fp32, gen_bf16):
+    d = np.load(os.path.join(golden_dir, "hifigan_v1_ragged.npz"))
+    lengths = [int(t) for t in d["lengths"]]
+    Tmax = max(lengths) + 5  # extra padding columns must not matter
+    mel = np.full((len(lengths), 80, Tmax), 3.0, np.float32)  # garbage in the padding on purpose
+    for b, T in enumerate(lengths):
+        mel[b, :, :T] = synth.synthetic_mel(T, int(d["mel_seed"]) + b)
+    x = torch.from_numpy(mel).cuda()
+    y = gen_fp32(x, lengths=lengths)[:, 0].cpu().numpy()
+    yb = gen_bf16(x, lengths=torch.tensor(lengths))[:, 0].cpu().numpy()
+    for b, T in enumerate(lengths):
+        assert np.abs(y[b, :T * 256] - d[f"wav.{b}"]).max() <= 1e-3
+        assert (y[b, T * 256:] == 0).all()
+        assert _snr(d[f"wav.{b}"], yb[b, :T * 256]) >= 40.0
+    # batch-1 call on the un-padded mel gives the same samples as the padded batch row
+    y1 = gen_fp32(torch.from_numpy(mel[0:1, :, :lengths[0]]).cuda())[0, 0].cpu().numpy()
+    assert np.abs(y1 - y[0, :lengths[0] * 256]).max() <= 1e-6
+
+
+def test_small_width_vs_oracle(golden_dir):
+    cfg = copy.deepcopy(synth.HIFIGAN_V1)
+    cfg["upsample_initial_channel"] = 64
+    d = np.load(os.path.join(golden_dir, "hifigan_c64_T48.npz"))
+    g = _gen(cfg, int(d["weight_seed"]), "fp32", weight_norm=False)
+    mel = synth.synthetic_mel(48, int(d["mel_seed"]))
+    y = g(torch.from_numpy(mel).cuda())[0].cpu().numpy()
+    assert np.abs(y - d["wav"]).max() <= 1e-3
+    ref = c_oracle.hifigan_forward(synth.hifigan_state(cfg, int(d["weight_seed"])), cfg, mel)
+    assert np.abs(y - ref).max() <= 1e-4
+
+
+def test_pcm16_output(golden_dir, gen_fp32):
+    mel = torch.from_numpy(synth.synthetic_mel(64, 1234)).cuda()
+    yf = gen_fp32(mel)[0]
+    yp = gen_fp32(mel, out="pcm16")[0]
+    assert yp.dtype == torch.int16
+    want = c_oracle.pcm16(yf.cpu().numpy())
+    assert np.array_equal(yp.cpu().numpy(), want)
+    g = np.load(os.path.join(golden_dir, "pcm16_v1_T64.npz"))["pcm"]
+    assert np.abs(yp.cpu().numpy().astype(np.int32) - g.astype(np.int32)).max() <= 33  # 1e-3 * 32768
+
+
+def test_edge_lengths(gen_fp32):
+    # T = 1 frame, and a batch holding an empty sequence
+    st = synth.hifigan_state(synth.HIFIGAN_V1, 0)
+    mel1 = synth.synthetic_mel(1, 9)
+    y = gen_fp32(torch.from_numpy(mel1).cuda())[0].cpu().numpy()
+    assert np.abs(y - c_oracle.hifigan_forward(st, synth.HIFIGAN_V1, mel1)).max() <= 1e-3
+    mel = torch.from_numpy(np.stack([synth.synthetic_mel(7, 3), synth.synthetic_mel(7, 4)])).cuda()
+    y = gen_fp32(mel, lengths=[0, 7])[:, 0].cpu().numpy()
+    assert (y[0] == 0).all()
+    assert np.abs(y[1] - c_oracle.hifigan_forward(st, synth.HIFIGAN_V1, synth.synthetic_mel(7, 4))).max() <= 1e-3
+
+
+def test_errors_are_loud(gen_fp32):
+    with pytest.raises(RuntimeError):
+        gen_fp32(torch.zeros(1, 80, 8))  # CPU tensor: no fallback
+    with pytest.raises(RuntimeError):
+        gen_fp32(torch.zeros(1, 79, 8, device="cuda"))
+    with pytest.raises(RuntimeError):
+        gen_fp32(torch.zeros(2, 80, 8, device="cuda"), lengths=[9, 1])
