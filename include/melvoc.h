@@ -142,6 +142,21 @@ MV_API void mv_destroy(mv_handle h);
  * device buffer of n samples, on device. */
 MV_API int mv_pcm16(const float* wav, size_t n, int16_t* pcm, void* stream);
 
+/* ---- measurement: per-launch HIP-event timing of the MFMA kernels (bench.py's roofline figure).
+ * No counterpart in the reference.  After mv_profile_begin(h) every convolution launch of the
+ * following forward/infer calls is bracketed by hipEventRecord on the call's stream;
+ * mv_profile_end(h, ...) synchronises those events, sums them per kernel instantiation and
+ * switches profiling off.  macs_per_frame is the ALGORITHMIC (un-padded) multiply-accumulate count
+ * per mel frame summed over the recorded launches: flops = 2 * macs_per_frame * frames of the batch. */
+typedef struct mv_profile_row {
+    char name[96];
+    int launches;
+    double ms;
+    double macs_per_frame;
+} mv_profile_row;
+MV_API int mv_profile_begin(mv_handle h);
+MV_API int mv_profile_end(mv_handle h, mv_profile_row* rows, int max_rows, int* n_rows);
+
 /* ---- test hooks: single layers through the same kernels the forward path launches ----------
  * No counterpart in the reference; they let tests/ compare one convolution against the oracle.
  *   x   device float32 channels-last [B][L][Cin]   y  device float32 channels-last [B][Lout][Cout]

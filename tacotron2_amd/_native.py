@@ -21,7 +21,7 @@ PRECISIONS = {"fp32": PREC_FP32, "float32": PREC_FP32, "bf16": PREC_BF16, "bfloa
 EXPORTS = (
     "mv_backend", "mv_last_error", "mv_hifigan_create", "mv_hifigan_forward", "mv_waveglow_create",
     "mv_waveglow_infer", "mv_workspace_bytes", "mv_hop", "mv_macs_per_frame", "mv_destroy", "mv_pcm16",
-    "mv_test_conv1d", "mv_test_conv_transpose1d",
+    "mv_test_conv1d", "mv_test_conv_transpose1d", "mv_profile_begin", "mv_profile_end",
 )
 
 
@@ -59,6 +59,10 @@ class mv_waveglow_cfg(C.Structure):
     ]
 
 
+class mv_profile_row(C.Structure):
+    _fields_ = [("name", C.c_char * 96), ("launches", C.c_int), ("ms", C.c_double), ("macs_per_frame", C.c_double)]
+
+
 _lib = None
 
 
@@ -78,6 +82,11 @@ def lib():
         raise MelvocError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C tacotron2_amd/csrc`). There is no CPU fallback.")
+    # PyTorch-ROCm bundles its own libamdhip64.so.7; load it first so that libmelvoc.so binds to the
+    # SAME HIP runtime as the tensors and streams it is handed (two runtimes in one process cannot
+    # share device pointers).
+    import torch  # noqa: F401
+
     l = C.CDLL(LIB_PATH)
     vp, i32, f32p = C.c_void_p, C.c_int, C.POINTER(C.c_float)
     l.mv_backend.restype = i32
@@ -96,6 +105,8 @@ def lib():
     l.mv_pcm16.argtypes = [vp, C.c_size_t, vp, vp]
     l.mv_test_conv1d.argtypes = [vp, vp, i32, i32, i32, f32p, f32p, i32, i32, i32, C.c_float, i32, vp, vp]
     l.mv_test_conv_transpose1d.argtypes = [vp, vp, i32, i32, i32, f32p, f32p, i32, i32, i32, i32, C.c_float, i32, vp, vp]
+    l.mv_profile_begin.argtypes = [vp]
+    l.mv_profile_end.argtypes = [vp, C.POINTER(mv_profile_row), i32, C.POINTER(i32)]
     _lib = l
     return l
 
@@ -178,6 +189,17 @@ class Handle:
 
     def workspace_bytes(self, B, Tmax):
         return lib().mv_workspace_bytes(self.ptr, int(B), int(Tmax))
+
+    def profile_begin(self):
+        check(lib().mv_profile_begin(self.ptr), "mv_profile_begin")
+
+    def profile_end(self):
+        """-> list of dicts {name, launches, ms, macs_per_frame} per kernel instantiation."""
+        rows = (mv_profile_row * 64)()
+        n = C.c_int(0)
+        check(lib().mv_profile_end(self.ptr, rows, 64, C.byref(n)), "mv_profile_end")
+        return [dict(name=rows[i].name.decode(), launches=rows[i].launches, ms=rows[i].ms,
+                     macs_per_frame=rows[i].macs_per_frame) for i in range(n.value)]
 
 
 def create_hifigan(cfg, state, device_index: int, precision: int) -> Handle:

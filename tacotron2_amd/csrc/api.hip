@@ -9,7 +9,7 @@ int build_convT_layer(Layer* L, const HostTensor* w, const HostTensor* b, int Ci
                       int cout_pad, bool bf16, int force_cfg);
 int launch_convT(const Layer& L, const float* x, long long x_bs, int cin_stride, int rows_per_frame, float slope,
                  float* y, long long y_bs, int cout_pad, int K, int u, int pad, const int32_t* lengths, int B,
-                 int Tmax, hipStream_t stream);
+                 int Tmax, hipStream_t stream, Profiler* prof);
 }  // namespace mv
 
 using namespace mv;
@@ -41,6 +41,45 @@ int mv_pcm16(const float* wav, size_t n, int16_t* pcm, void* stream) {
         return MV_EINVAL;
     }
     return launch_pcm16(wav, n, pcm, (hipStream_t)stream);
+}
+
+int mv_profile_begin(mv_handle h) {
+    if (!h) {
+        set_error("mv_profile_begin: null handle");
+        return MV_EINVAL;
+    }
+    DeviceGuard g(h->device);
+    h->prof.release();
+    h->prof.on = true;
+    return MV_OK;
+}
+
+int mv_profile_end(mv_handle h, mv_profile_row* rows, int max_rows, int* n_rows) {
+    if (!h || !rows || !n_rows || max_rows < 1) {
+        set_error("mv_profile_end: bad argument");
+        return MV_EINVAL;
+    }
+    DeviceGuard g(h->device);
+    std::map<std::string, mv_profile_row> acc;
+    for (auto& r : h->prof.recs) {
+        MV_HIP(hipEventSynchronize(r.e1));
+        float ms = 0.f;
+        MV_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
+        mv_profile_row& row = acc[r.name];
+        if (row.launches == 0) {
+            memset(&row, 0, sizeof row);
+            snprintf(row.name, sizeof row.name, "%s", r.name.c_str());
+        }
+        row.launches += 1;
+        row.ms += ms;
+        row.macs_per_frame += r.macs_per_frame;
+    }
+    int n = 0;
+    for (auto& kv : acc)
+        if (n < max_rows) rows[n++] = kv.second;
+    *n_rows = n;
+    h->prof.release();
+    return MV_OK;
 }
 
 static int test_cfg() {
@@ -95,7 +134,7 @@ int mv_test_conv_transpose1d(const float* x, const int32_t* lengths, int B, int 
                            test_cfg());
     if (rc) return rc;
     rc = launch_convT(Lr, x, (long long)L * Cin, Cin, 1, pre_slope, y, (long long)L * stride * Cout, Cout, K, stride,
-                      padding, lengths, B, L, (hipStream_t)stream);
+                      padding, lengths, B, L, (hipStream_t)stream, nullptr);
     hipError_t e = hipStreamSynchronize((hipStream_t)stream);
     free_layer(&Lr);
     if (rc) return rc;

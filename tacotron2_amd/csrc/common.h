@@ -56,7 +56,25 @@ struct Layer {
     int epi = EPI_LINEAR;
     size_t lds_bytes = 0;
     double macs_per_n = 0;  // padded MACs per output row (diagnostics)
+    double alg_macs_per_n = 0;  // algorithmic (un-padded) MACs per output row, set by the model builders
 };
+
+// Per-launch HIP-event timing, off unless mv_profile_begin() was called on the handle.
+struct Profiler {
+    struct Rec {
+        std::string name;
+        double macs_per_frame;
+        hipEvent_t e0, e1;
+    };
+    bool on = false;
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t get();
+    void begin(hipStream_t s, const std::string& name, double macs_per_frame);
+    void end(hipStream_t s);
+    void release();
+};
+std::string layer_kernel_name(const Layer& L);
 
 // One logical input of a layer: C channels (already padded to the k-chunk), taps, and the weight
 // as a function (m, tap, c) -> float in the *kernel's* tap order (input row = n + tap*dil - pad_left).
@@ -93,7 +111,8 @@ struct LaunchArgs {
     float div = 1.f;
 };
 
-int launch_layer(const Layer& L, const SrcBind* srcs, int nsrc, const LaunchArgs& a, hipStream_t stream);
+int launch_layer(const Layer& L, const SrcBind* srcs, int nsrc, const LaunchArgs& a, hipStream_t stream,
+                 Profiler* prof = nullptr);
 int init_kernel_attributes();
 
 // ---- weight lookup (state-dict names, weight-norm folding) --------------------------------

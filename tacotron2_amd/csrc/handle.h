@@ -6,7 +6,8 @@ struct mv_handle_s {
     int kind = 0;  // 1 = HiFi-GAN generator, 2 = WaveGlow
     int device = 0;
     int precision = MV_PREC_FP32;
-    virtual ~mv_handle_s() {}
+    mv::Profiler prof;
+    virtual ~mv_handle_s() { prof.release(); }
     virtual size_t workspace_bytes(int B, int Tmax) const = 0;
     virtual int hop() const = 0;
     virtual double macs_per_frame() const = 0;

@@ -166,7 +166,7 @@ int build_convT_layer(Layer* L, const HostTensor* w, const HostTensor* b, int Ci
 // Launch a transposed-conv layer built by build_convT_layer.
 int launch_convT(const Layer& L, const float* x, long long x_bs, int cin_stride, int rows_per_frame, float slope,
                  float* y, long long y_bs, int cout_pad, int K, int u, int pad, const int32_t* lengths, int B,
-                 int Tmax, hipStream_t stream) {
+                 int Tmax, hipStream_t stream, Profiler* prof) {
     const int J = (K + u - 1) / u;
     SrcBind sb{x, x_bs, cin_stride, rows_per_frame, slope};
     LaunchArgs a;
@@ -181,7 +181,7 @@ int launch_convT(const Layer& L, const float* x, long long x_bs, int cin_stride,
     a.out[0].off = -(long long)pad * cout_pad;
     a.out[0].valid_per_frame = (long long)rows_per_frame * u * cout_pad;
     a.out[0].mode = ACC_STORE;
-    return launch_layer(L, &sb, 1, a, stream);
+    return launch_layer(L, &sb, 1, a, stream, prof);
 }
 
 static int hifigan_build(HifiganHandle* h, WeightMap& W) {
@@ -206,6 +206,7 @@ static int hifigan_build(HifiganHandle* h, WeightMap& W) {
         const HostTensor* b = W.get("conv_pre.bias");
         if ((rc = bias_check(b, h->C[0], "conv_pre.bias"))) return rc;
         if ((rc = build_conv1d_layer(&h->pre, w, b, c.num_mels, h->C[0], 7, 1, h->melp, h->Cp[0], bf16))) return rc;
+        h->pre.alg_macs_per_n = (double)h->C[0] * c.num_mels * 7;
         macs += (double)h->C[0] * c.num_mels * 7;
     }
     h->ups.resize(h->nstage);
@@ -225,6 +226,7 @@ static int hifigan_build(HifiganHandle* h, WeightMap& W) {
         if ((rc = bias_check(b, h->C[i + 1], name))) return rc;
         if ((rc = build_convT_layer(&h->ups[i], w, b, h->C[i], h->C[i + 1], K, u, h->Cp[i], h->Cp[i + 1], bf16)))
             return rc;
+        h->ups[i].alg_macs_per_n = (double)h->C[i] * h->C[i + 1] * K;
         macs += rows * (double)h->C[i] * h->C[i + 1] * K;  // every input row meets all K taps
         rows *= u;
         const int Cc = h->C[i + 1], Ccp = h->Cp[i + 1];
@@ -248,6 +250,7 @@ static int hifigan_build(HifiganHandle* h, WeightMap& W) {
                     if ((rc = build_conv1d_layer(which ? &pr.c2 : &pr.c1, cw, cb, Cc, Cc, k, which ? 1 : d, Ccp, Ccp,
                                                  bf16)))
                         return rc;
+                    (which ? pr.c2 : pr.c1).alg_macs_per_n = (double)Cc * Cc * k;
                     macs += rows * (double)Cc * Cc * k;
                 }
             }
@@ -279,6 +282,7 @@ static int hifigan_forward(HifiganHandle* h, const float* mel, const int32_t* le
         return MV_ENOMEM;
     }
     int rc;
+    Profiler* prof = h->prof.on ? &h->prof : nullptr;
     const size_t bt = (size_t)B * Tmax;
     char* ws = (char*)workspace;
     float* X0 = (float*)ws;
@@ -297,7 +301,7 @@ static int hifigan_forward(HifiganHandle* h, const float* mel, const int32_t* le
         a.B = B;
         a.Tmax = Tmax;
         a.out[0] = ConvOut{PRE, (long long)Tmax * h->Cp[0], 0, h->Cp[0], h->Cp[0], ACC_STORE};
-        if ((rc = launch_layer(h->pre, &sb, 1, a, stream))) return rc;
+        if ((rc = launch_layer(h->pre, &sb, 1, a, stream, prof))) return rc;
     }
     const float* cur_in = PRE;  // input of the next upsampling
     int rpf = 1;                // rows per mel frame of cur_in
@@ -314,7 +318,7 @@ static int hifigan_forward(HifiganHandle* h, const float* mel, const int32_t* le
         const long long bs_in = (long long)Tmax * rpf * Cin_p;
         const long long bs = (long long)Tmax * rpf_out * Cp;
         if ((rc = launch_convT(h->ups[i], cur_in, bs_in, Cin_p, rpf, 0.1f, A, bs, Cp, K, u, (K - u) / 2, lengths, B,
-                               Tmax, stream)))
+                               Tmax, stream, prof)))
             return rc;
         for (int j = 0; j < c.num_kernels; ++j) {
             const float* cur = A;
@@ -327,7 +331,7 @@ static int hifigan_forward(HifiganHandle* h, const float* mel, const int32_t* le
                 a.n_rows_per_frame = rpf_out;
                 a.out[0] = ConvOut{T1, bs, 0, (long long)rpf_out * Cp, Cp, ACC_STORE};
                 SrcBind s1{cur, bs, Cp, rpf_out, 0.1f};
-                if ((rc = launch_layer(pr.c1, &s1, 1, a, stream))) return rc;
+                if ((rc = launch_layer(pr.c1, &s1, 1, a, stream, prof))) return rc;
                 SrcBind s2{T1, bs, Cp, rpf_out, 0.1f};
                 a.resid = cur;
                 a.resid_batch_stride = bs;
@@ -339,7 +343,7 @@ static int hifigan_forward(HifiganHandle* h, const float* mel, const int32_t* le
                     a.out[0].mode = j == 0 ? ACC_STORE : (j == c.num_kernels - 1 ? ACC_ADD_DIV : ACC_ADD);
                     if (c.num_kernels == 1) a.out[0].mode = ACC_STORE;
                 }
-                if ((rc = launch_layer(pr.c2, &s2, 1, a, stream))) return rc;
+                if ((rc = launch_layer(pr.c2, &s2, 1, a, stream, prof))) return rc;
                 cur = PQ[m & 1];
             }
         }

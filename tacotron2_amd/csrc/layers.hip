@@ -194,7 +194,48 @@ int init_kernel_attributes() {
     return MV_OK;
 }
 
-int launch_layer(const Layer& L, const SrcBind* srcs, int nsrc, const LaunchArgs& a, hipStream_t stream) {
+hipEvent_t Profiler::get() {
+    if (!pool.empty()) {
+        hipEvent_t e = pool.back();
+        pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+void Profiler::begin(hipStream_t s, const std::string& name, double macs_per_frame) {
+    if (!on) return;
+    Rec r{name, macs_per_frame, get(), get()};
+    (void)hipEventRecord(r.e0, s);
+    recs.push_back(r);
+}
+void Profiler::end(hipStream_t s) {
+    if (!on || recs.empty()) return;
+    (void)hipEventRecord(recs.back().e1, s);
+}
+void Profiler::release() {
+    for (auto& r : recs) {
+        pool.push_back(r.e0);
+        pool.push_back(r.e1);
+    }
+    recs.clear();
+    for (hipEvent_t e : pool)
+        if (e) (void)hipEventDestroy(e);
+    pool.clear();
+    on = false;
+}
+
+std::string layer_kernel_name(const Layer& L) {
+    const TileCfg& tc = kTileCfgs[L.cfg];
+    char buf[128];
+    snprintf(buf, sizeof buf, "conv_cl_kernel<%s,TM%d,TN%d,WM%d,WN%d,%s>", L.bf16 ? "bf16" : "fp32", tc.TM, tc.TN, tc.WM,
+             tc.WN, L.epi == EPI_GATE ? "gate" : "linear");
+    return buf;
+}
+
+int launch_layer(const Layer& L, const SrcBind* srcs, int nsrc, const LaunchArgs& a, hipStream_t stream,
+                 Profiler* prof) {
     const TileCfg& tc = kTileCfgs[L.cfg];
     ConvParams p;
     memset(&p, 0, sizeof p);
@@ -241,7 +282,9 @@ int launch_layer(const Layer& L, const SrcBind* srcs, int nsrc, const LaunchArgs
     dim3 grid((unsigned)((n_max + tc.NT() - 1) / tc.NT()), (unsigned)(L.M / tc.MT()), (unsigned)a.B);
     dim3 block(tc.WM * tc.WN * 64);
     ConvKernel k = pick_kernel(L.bf16, L.epi, L.cfg);
+    if (prof) prof->begin(stream, layer_kernel_name(L), L.alg_macs_per_n * a.n_rows_per_frame);
     hipLaunchKernelGGL(k, grid, block, L.lds_bytes, stream, p);
+    if (prof) prof->end(stream);
     MV_HIP(hipGetLastError());
     return MV_OK;
 }

@@ -232,6 +232,7 @@ static int waveglow_build(WaveglowHandle* h, WeightMap& W) {
         for (int m = 0; m < M; ++m) bias[m] = b->data[(m % per_row) / ng];
         // always exact fp32: 0.08 % of the FLOPs, and it feeds every flow
         if ((rc = build_layer(&h->up, {s}, M, bias, false, EPI_LINEAR))) return rc;
+        h->up.alg_macs_per_n = (double)nm * nm * K;
     }
     h->flows.resize(c.n_flows);
     int n_half = ng / 2, n_rem = ng;
@@ -316,6 +317,7 @@ static int waveglow_build(WaveglowHandle* h, WeightMap& W) {
             std::vector<float> bias(2 * C);
             for (int m = 0; m < 2 * C; ++m) bias[m] = ib->data[orig(m)] + cbd[orig(m)];
             if ((rc = build_layer(&f.in_layers[i], {sh, sc}, 2 * C, bias, bf16, EPI_GATE))) return rc;
+            f.in_layers[i].alg_macs_per_n = (double)2 * C * C * ks + (double)2 * C * h->ncond;
 
             const int rsC = i < nl - 1 ? 2 * C : C;
             snprintf(name, sizeof name, "WN.%d.res_skip_layers.%d.weight", k, i);
@@ -332,6 +334,7 @@ static int waveglow_build(WaveglowHandle* h, WeightMap& W) {
             sa.pad_left = 0;
             sa.w = [=](int m, int, int ci) -> float { return ci < C ? rwd[(size_t)m * C + ci] : 0.f; };
             if ((rc = build_layer(&f.res_skip[i], {sa}, rsC, rb->data, bf16, EPI_LINEAR))) return rc;
+            f.res_skip[i].alg_macs_per_n = (double)rsC * C;
         }
         macs_step += (double)n_half * C + (double)h->ncond * 2 * C * nl + (double)nl * 2 * C * C * ks +
                      ((double)(nl - 1) * 2 * C * C + (double)C * C) + (double)C * 2 * n_half + (double)n_rem * n_rem;
@@ -366,6 +369,7 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
             return MV_EINVAL;
         }
     int rc;
+    Profiler* prof = h->prof.on ? &h->prof : nullptr;
     const size_t bl = (size_t)B * L;
     char* ws = (char*)workspace;
     float* X0 = (float*)ws;
@@ -393,7 +397,7 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
         a.n_extra = 3;
         const long long per_frame = (long long)spf * h->ncond;  // = 256 * n_mel
         a.out[0] = ConvOut{SPECT, (long long)Tmax * per_frame, 0, per_frame, (int)per_frame, ACC_STORE};
-        if ((rc = launch_layer(h->up, &sb, 1, a, stream))) return rc;
+        if ((rc = launch_layer(h->up, &sb, 1, a, stream, prof))) return rc;
     }
     {
         dim3 grid((L + 255) / 256, B);
@@ -420,7 +424,7 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
             a.Tmax = Tmax;
             a.n_rows_per_frame = spf;
             a.out[0] = ConvOut{ACTS, bsC, 0, (long long)spf * Cp, Cp, ACC_STORE};
-            if ((rc = launch_layer(f.in_layers[i], sb, 2, a, stream))) return rc;
+            if ((rc = launch_layer(f.in_layers[i], sb, 2, a, stream, prof))) return rc;
             SrcBind sa{ACTS, bsC, Cp, spf, 1.0f};
             LaunchArgs r;
             r.lengths = lengths;
@@ -435,7 +439,7 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
             } else {
                 r.out[0] = ConvOut{SKIP, bsC, 0, (long long)spf * Cp, Cp, skip_mode};
             }
-            if ((rc = launch_layer(f.res_skip[i], &sa, 1, r, stream))) return rc;
+            if ((rc = launch_layer(f.res_skip[i], &sa, 1, r, stream, prof))) return rc;
         }
         const bool early = k % c.n_early_every == 0 && k > 0;
         {

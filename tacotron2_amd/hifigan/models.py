@@ -191,6 +191,16 @@ class Generator(nn.Module):
             self._workspace[dev] = ws
         return ws
 
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        d["_handles"], d["_workspace"] = {}, {}
+        return d
+
+    def native_handle(self, dev=None):
+        """The _native.Handle serving `dev` (built on first use); bench.py profiles through it."""
+        dev = torch.device(dev) if dev is not None else next(self.parameters()).device
+        return self._handle(dev)
+
     def macs_per_frame(self, dev=None):
         dev = dev or next(self.parameters()).device
         return self._handle(dev).macs_per_frame
