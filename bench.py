@@ -161,6 +161,11 @@ def main():
         torch.cuda.synchronize()
         rows = h.profile_end()
         rows.sort(key=lambda r: -r["ms"])
+        if os.environ.get("MELVOC_BENCH_ROWS"):
+            for r in rows:
+                print("# %-48s launches/step %3d  ms/step %8.3f  TFLOP/s %7.1f" % (
+                    r["name"], r["launches"] // nprof, r["ms"] / nprof,
+                    2.0 * r["macs_per_frame"] * frames / max(r["ms"], 1e-9) / 1e9), file=sys.stderr)
         top = rows[0]
         flops = 2.0 * top["macs_per_frame"] * frames  # over all recorded launches of that kernel
         achieved = flops / (top["ms"] * 1e-3) / 1e12

@@ -130,57 +130,60 @@ __device__ __forceinline__ void stage_tile(char* smem, const ConvPass& cp, const
     }
 }
 
+// One K step: every N tile's B fragment (LDS) against the TM resident A fragments.
+template <bool BF16, int TM, int TN>
+__device__ __forceinline__ void mma_step(f32x4 (&acc)[TM][TN], const u32x4 (&a)[TM], const char* bp, int RS) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const u32x4 b = *(const u32x4*)(bp + tn * 16 * RS);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) mma16<BF16>(acc[tm][tn], a[tm], b);
+    }
+}
+
 // One pass of the K loop: S = ktaps * nkc steps; A fragments stream from global two steps ahead.
+// The loop body is branch-free (prefetch indices are clamped, not guarded) so the accumulators stay
+// in place in the register file.
 template <bool BF16, int TM, int TN>
 __device__ __forceinline__ void mma_pass(f32x4 (&acc)[TM][TN], const char* lds_b, int RS, int ktaps, int dil, int nkc,
                                          const u32x4* wlane, long long mtile_stride) {
     const int S = ktaps * nkc;
-    const int tap_bytes = dil * RS;
+    const int tap_wrap = dil * RS - nkc * 64;
     u32x4 a0[TM], a1[TM];
+    const int s1 = S > 1 ? 1 : 0;
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) a0[tm] = wlane[tm * mtile_stride];
-    if (S > 1) {
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) a1[tm] = wlane[tm * mtile_stride + 64];
+    for (int tm = 0; tm < TM; ++tm) {
+        a0[tm] = wlane[tm * mtile_stride];
+        a1[tm] = wlane[tm * mtile_stride + s1 * 64];
     }
     int kc = 0;
     const char* bp = lds_b;  // advances 64 B per k-chunk, wraps to the next tap
-    auto advance = [&]() {
-        ++kc;
-        bp += 64;
-        if (kc == nkc) {
-            kc = 0;
-            bp += tap_bytes - nkc * 64;
-        }
-    };
-    for (int s = 0; s < S; s += 2) {
+    int s = 0;
+    for (; s + 2 <= S; s += 2) {
+        mma_step<BF16, TM, TN>(acc, a0, bp, RS);
         {
+            const int sn = s + 2 < S ? s + 2 : S - 1;
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                const u32x4 b = *(const u32x4*)(bp + tn * 16 * RS);
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm) mma16<BF16>(acc[tm][tn], a0[tm], b);
-            }
-            advance();
-            if (s + 2 < S) {
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm) a0[tm] = wlane[tm * mtile_stride + (long long)(s + 2) * 64];
-            }
+            for (int tm = 0; tm < TM; ++tm) a0[tm] = wlane[tm * mtile_stride + (long long)sn * 64];
         }
-        if (s + 1 < S) {
+        bp += 64;
+        if (++kc == nkc) {
+            kc = 0;
+            bp += tap_wrap;
+        }
+        mma_step<BF16, TM, TN>(acc, a1, bp, RS);
+        {
+            const int sn = s + 3 < S ? s + 3 : S - 1;
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                const u32x4 b = *(const u32x4*)(bp + tn * 16 * RS);
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm) mma16<BF16>(acc[tm][tn], a1[tm], b);
-            }
-            advance();
-            if (s + 3 < S) {
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm) a1[tm] = wlane[tm * mtile_stride + (long long)(s + 3) * 64];
-            }
+            for (int tm = 0; tm < TM; ++tm) a1[tm] = wlane[tm * mtile_stride + (long long)sn * 64];
+        }
+        bp += 64;
+        if (++kc == nkc) {
+            kc = 0;
+            bp += tap_wrap;
         }
     }
+    if (s < S) mma_step<BF16, TM, TN>(acc, a0, bp, RS);
 }
 
 __device__ __forceinline__ void store_out(const ConvOut& o, int b, long long e, long long valid, f32x4 v,

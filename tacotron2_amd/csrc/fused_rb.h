@@ -1,0 +1,212 @@
+// fused_rb.h -- fused ResBlock1 kernel (bf16 operands), hifigan/models.py:96-103 of the reference.
+//
+// One block owns a WINDOW of W consecutive time rows of one sequence (all C channels) and runs
+// NPAIR consecutive (dilated conv, conv) pairs on it without leaving the CU:
+//
+//     A16 = bf16(lrelu(x))                         LDS, [W + 2*guardA][C]
+//     for each pair m:   Y16 = bf16(lrelu(conv1_m(A16) + b1))      LDS, [W + 2*guardY][C]
+//                        x   = x + conv2_m(Y16) + b2               fp32
+//                        A16 = bf16(lrelu(x))
+//     out = MRF-combine(x)   for the rows the halo has not eaten
+//
+// Every conv is computed over the whole window; rows closer than H = sum of the pairs' halos to a
+// window edge are wrong after the last pair and are simply not written, so a block emits
+// NT = W - 2H rows (blocks overlap by 2H input rows).  Rows outside [0, len) of the sequence are
+// forced to zero in A16 / Y16, which is exactly the zero padding each conv of the reference's
+// batch-1 call sees.  HBM traffic per ResBlock drops from 15 activation passes (6 convs unfused)
+// to ~2.3 with NPAIR = 3, ~7 with NPAIR = 1.
+//
+// XREG = true : the fp32 residual stream x lives in registers in MFMA accumulator layout (each
+//               wave keeps x for exactly the (channel, row) tiles it accumulates), NPAIR may be 3.
+// XREG = false: NPAIR must be 1; x is staged once (coalesced) and re-read from L2 for the residual.
+//
+// Waves: WM x WN; wave (wm, wn) owns M tiles [wm*TM, +TM) (TM = C/16/WM) and N tiles [wn*TN, +TN).
+// Weights stream L2 -> registers in A-fragment order exactly as in conv_mfma.h.
+#pragma once
+#include "conv_mfma.h"
+
+namespace mv {
+
+struct FusedRbParams {
+    const float* x;   // [B][rows][C] fp32
+    float* out;       // same layout
+    long long batch_stride;
+    const int32_t* lengths;
+    int Tmax;
+    int rows_per_frame;
+    int K;        // kernel size of every conv in this ResBlock
+    int npair;    // pairs run by this launch (1 or 3)
+    int dil[3];
+    const void* w1[3];
+    const void* w2[3];
+    const float* b1[3];
+    const float* b2[3];
+    int mode;     // ACC_* for the final store (MRF accumulation)
+    float div;
+    int NT;       // rows written per block = W - 2*H
+    int H;        // sum over pairs of (K-1)/2 * (dil+1)
+    int guardA;   // max over pairs of dil*(K-1)/2
+    int guardY;   // (K-1)/2
+};
+
+template <int TM, int TN>
+__device__ __forceinline__ void conv_window(f32x4 (&acc)[TM][TN], const char* lds_b, int RS, int ktaps, int dil,
+                                            int nkc, const u32x4* wlane, long long mtile_stride) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+    mma_pass<true, TM, TN>(acc, lds_b, RS, ktaps, dil, nkc, wlane, mtile_stride);
+}
+
+__device__ __forceinline__ unsigned long long pack4_bf16_lrelu(const f32x4& v, float slope, bool keep) {
+    const unsigned lo = pack_bf16(lrelu(v[0], slope), lrelu(v[1], slope));
+    const unsigned hi = pack_bf16(lrelu(v[2], slope), lrelu(v[3], slope));
+    return keep ? ((unsigned long long)hi << 32) | lo : 0ull;
+}
+
+template <int C, int WM, int WN, int TN, bool XREG>
+__global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbParams p) {
+    constexpr int TM = C / 16 / WM;
+    constexpr int W = 16 * TN * WN;
+    constexpr int NTHREADS = WM * WN * 64;
+    constexpr int RS = C * 2 + kLdsRowPad;
+    constexpr int NKC = C / 32;
+    static_assert(TM * 16 * WM == C, "C must split evenly over the M waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int b = blockIdx.y;
+    const int len = (p.lengths ? p.lengths[b] : p.Tmax) * p.rows_per_frame;
+    const int out0 = blockIdx.x * p.NT;  // first row this block writes
+    if (out0 >= len) return;
+    const int t0 = out0 - p.H;           // global row of window row 0
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int lr = lane & 15, lg = lane >> 4;
+
+    char* A16 = smem;                                   // rows [-guardA, W + guardA)
+    char* Y16 = smem + (W + 2 * p.guardA) * RS;         // rows [-guardY, W + guardY)
+    const float* xb = p.x + (long long)b * p.batch_stride;
+
+    // zero the guard rows once (they stand for rows outside the window; their values only reach
+    // outputs inside the halo, but they must be finite)
+    {
+        const int upr = RS / 16;
+        for (int idx = threadIdx.x; idx < 2 * p.guardA * upr; idx += NTHREADS) {
+            const int r = idx / upr, u = idx - r * upr;
+            const int row = r < p.guardA ? r : W + r;  // [0,guardA) and [W+guardA, W+2guardA)
+            *(u32x4*)(A16 + row * RS + u * 16) = u32x4{0u, 0u, 0u, 0u};
+        }
+        for (int idx = threadIdx.x; idx < 2 * p.guardY * upr; idx += NTHREADS) {
+            const int r = idx / upr, u = idx - r * upr;
+            const int row = r < p.guardY ? r : W + r;
+            *(u32x4*)(Y16 + row * RS + u * 16) = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    char* A0 = A16 + p.guardA * RS;  // window row 0
+    char* Y0 = Y16 + p.guardY * RS;
+
+    f32x4 X[XREG ? TM : 1][XREG ? TN : 1];
+    if constexpr (XREG) {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int n = (wn * TN + tn) * 16 + lr;
+            const int g = t0 + n;
+            const bool in_seq = g >= 0 && g < len;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int ch = (wm * TM + tm) * 16 + lg * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (in_seq) v = *(const f32x4*)(xb + (long long)g * C + ch);
+                X[tm][tn] = v;
+                *(unsigned long long*)(A0 + n * RS + ch * 2) = pack4_bf16_lrelu(v, 0.1f, in_seq);
+            }
+        }
+    } else {
+        ConvPass cp;
+        cp.row_stride = C;
+        cp.cin_off = 0;
+        cp.cb = C;
+        cp.slope = 0.1f;
+        stage_tile<true, NTHREADS>(A0, cp, xb, t0, W, len, RS);
+    }
+
+    f32x4 acc[TM][TN];
+    const long long mtile_stride = (long long)p.K * NKC * 64;
+    const long long woff = (long long)(wm * TM) * mtile_stride + lane;
+    const int pad2 = (p.K - 1) / 2;
+
+    for (int m = 0; m < p.npair; ++m) {
+        const int d = p.dil[m];
+        const int pad1 = d * (p.K - 1) / 2;
+        __syncthreads();  // A16 complete
+        conv_window<TM, TN>(acc, A0 + ((wn * TN * 16 + lr) - pad1) * RS + lg * 16, RS, p.K, d, NKC,
+                            (const u32x4*)p.w1[m] + woff, mtile_stride);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int ch = (wm * TM + tm) * 16 + lg * 4;
+            const f32x4 bias = *(const f32x4*)(p.b1[m] + ch);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int n = (wn * TN + tn) * 16 + lr;
+                const int g = t0 + n;
+                *(unsigned long long*)(Y0 + n * RS + ch * 2) =
+                    pack4_bf16_lrelu(acc[tm][tn] + bias, 0.1f, g >= 0 && g < len);
+            }
+        }
+        __syncthreads();  // Y16 complete, A16 free
+        conv_window<TM, TN>(acc, Y0 + ((wn * TN * 16 + lr) - pad2) * RS + lg * 16, RS, p.K, 1, NKC,
+                            (const u32x4*)p.w2[m] + woff, mtile_stride);
+        if constexpr (XREG) {
+            const bool more = m + 1 < p.npair;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int ch = (wm * TM + tm) * 16 + lg * 4;
+                const f32x4 bias = *(const f32x4*)(p.b2[m] + ch);
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const int n = (wn * TN + tn) * 16 + lr;
+                    const int g = t0 + n;
+                    X[tm][tn] = (acc[tm][tn] + bias) + X[tm][tn];
+                    if (more)
+                        *(unsigned long long*)(A0 + n * RS + ch * 2) =
+                            pack4_bf16_lrelu(X[tm][tn], 0.1f, g >= 0 && g < len);
+                }
+            }
+        }
+    }
+
+    // ---- store the rows the halo has not reached, with the MRF accumulation of models.py:154-160
+    float* ob = p.out + (long long)b * p.batch_stride;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int ch = (wm * TM + tm) * 16 + lg * 4;
+        f32x4 bias2 = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (!XREG) bias2 = *(const f32x4*)(p.b2[0] + ch);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int n = (wn * TN + tn) * 16 + lr;
+            const int g = t0 + n;
+            if (n < p.H || n >= p.H + p.NT || g >= len) continue;
+            const long long e = (long long)g * C + ch;
+            f32x4 v;
+            if constexpr (XREG)
+                v = X[tm][tn];
+            else
+                v = (acc[tm][tn] + bias2) + *(const f32x4*)(xb + e);
+            if (p.mode == ACC_ADD) {
+                v += *(const f32x4*)(ob + e);
+            } else if (p.mode == ACC_ADD_DIV) {
+                v += *(const f32x4*)(ob + e);
+                v[0] = v[0] / p.div;
+                v[1] = v[1] / p.div;
+                v[2] = v[2] / p.div;
+                v[3] = v[3] / p.div;
+            }
+            *(f32x4*)(ob + e) = v;
+        }
+    }
+}
+
+}  // namespace mv

@@ -14,9 +14,41 @@
 //   conv_post         lrelu(0.01) -> Conv1d(C,1,7) -> tanh   (models.py:161-163), fp32 VALU
 #include <cmath>
 
+#include "fused_rb.h"
 #include "handle.h"
 
 namespace mv {
+
+// ---- fused ResBlock launches (bf16 mode) ------------------------------------------------------
+typedef void (*FusedKernel)(const FusedRbParams);
+struct FusedCfg {
+    int C, W, threads, npair;
+    FusedKernel k;
+    const char* name;
+};
+//                         C   WM WN TN  XREG
+static const FusedCfg kFused[] = {
+    {32, 768, 256, 3, fused_rb_kernel<32, 1, 4, 12, true>, "fused_rb_kernel<C32,WM1,WN4,TN12,xreg>"},
+    {64, 320, 256, 3, fused_rb_kernel<64, 2, 2, 10, true>, "fused_rb_kernel<C64,WM2,WN2,TN10,xreg>"},
+    {128, 240, 256, 1, fused_rb_kernel<128, 4, 1, 15, false>, "fused_rb_kernel<C128,WM4,WN1,TN15,pair>"},
+};
+
+static const FusedCfg* fused_cfg_for(int Cp) {
+    static const int enabled = [] {
+        const char* s = getenv("MV_FUSE");
+        return s && *s ? atoi(s) : 1;
+    }();
+    if (!enabled) return nullptr;
+    for (const FusedCfg& f : kFused)
+        if (f.C == Cp) return &f;
+    return nullptr;
+}
+
+int init_fused_attributes() {
+    for (const FusedCfg& f : kFused)
+        MV_HIP(hipFuncSetAttribute((const void*)f.k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return MV_OK;
+}
 
 struct RbPair {
     Layer c1, c2;
@@ -273,6 +305,53 @@ static int hifigan_build(HifiganHandle* h, WeightMap& W) {
     return MV_OK;
 }
 
+// Runs pairs [m0, m0+npair) of one ResBlock fused; returns MV_EUNSUPPORTED if the window is too small.
+static int launch_fused_rb(const FusedCfg& fc, const RbPair* pairs, int m0, int npair, int K, const int* dils,
+                           const float* x, float* out, long long bs, int rpf, int mode, float div,
+                           const int32_t* lengths, int B, int Tmax, hipStream_t stream, Profiler* prof) {
+    FusedRbParams p;
+    memset(&p, 0, sizeof p);
+    p.x = x;
+    p.out = out;
+    p.batch_stride = bs;
+    p.lengths = lengths;
+    p.Tmax = Tmax;
+    p.rows_per_frame = rpf;
+    p.K = K;
+    p.npair = npair;
+    p.mode = mode;
+    p.div = div;
+    const int pad2 = (K - 1) / 2;
+    int H = 0, gA = 0;
+    double macs = 0;
+    for (int i = 0; i < npair; ++i) {
+        const RbPair& pr = pairs[m0 + i];
+        if (pr.c1.npass != 1 || pr.c2.npass != 1) return MV_EUNSUPPORTED;  // fused kernel wants [tap][kc] order
+        p.dil[i] = dils[m0 + i];
+        p.w1[i] = pr.c1.w;
+        p.w2[i] = pr.c2.w;
+        p.b1[i] = pr.c1.bias;
+        p.b2[i] = pr.c2.bias;
+        H += pad2 * (dils[m0 + i] + 1);
+        gA = std::max(gA, dils[m0 + i] * pad2);
+        macs += pr.c1.alg_macs_per_n + pr.c2.alg_macs_per_n;
+    }
+    p.H = H;
+    p.NT = fc.W - 2 * H;
+    p.guardA = gA;
+    p.guardY = pad2;
+    const int RS = fc.C * 2 + kLdsRowPad;
+    const size_t lds = (size_t)(2 * fc.W + 2 * gA + 2 * pad2) * RS;
+    if (p.NT < 16 || lds > 160 * 1024) return MV_EUNSUPPORTED;
+    const long long rows = (long long)Tmax * rpf;
+    dim3 grid((unsigned)((rows + p.NT - 1) / p.NT), (unsigned)B);
+    if (prof) prof->begin(stream, fc.name, macs * rpf);
+    hipLaunchKernelGGL(fc.k, grid, dim3(fc.threads), lds, stream, p);
+    if (prof) prof->end(stream);
+    MV_HIP(hipGetLastError());
+    return MV_OK;
+}
+
 static int hifigan_forward(HifiganHandle* h, const float* mel, const int32_t* lengths, int B, int Tmax, void* wav,
                            int out_format, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     const mv_hifigan_cfg& c = h->cfg;
@@ -320,10 +399,32 @@ static int hifigan_forward(HifiganHandle* h, const float* mel, const int32_t* le
         if ((rc = launch_convT(h->ups[i], cur_in, bs_in, Cin_p, rpf, 0.1f, A, bs, Cp, K, u, (K - u) / 2, lengths, B,
                                Tmax, stream, prof)))
             return rc;
+        const FusedCfg* fc = h->precision == MV_PREC_BF16 ? fused_cfg_for(Cp) : nullptr;
         for (int j = 0; j < c.num_kernels; ++j) {
             const float* cur = A;
+            const RbPair* pairs = &h->rb[((size_t)i * c.num_kernels + j) * 3];
+            const int acc_mode =
+                c.num_kernels == 1 || j == 0 ? ACC_STORE : (j == c.num_kernels - 1 ? ACC_ADD_DIV : ACC_ADD);
+            const int krb = c.resblock_kernel_sizes[j];
+            if (fc && fc->npair == 3) {
+                rc = launch_fused_rb(*fc, pairs, 0, 3, krb, c.resblock_dilations[j], A, ACC, bs, rpf_out, acc_mode,
+                                     (float)c.num_kernels, lengths, B, Tmax, stream, prof);
+                if (rc == MV_OK) continue;
+                if (rc != MV_EUNSUPPORTED) return rc;
+            }
             for (int m = 0; m < 3; ++m) {
-                const RbPair& pr = h->rb[((size_t)i * c.num_kernels + j) * 3 + m];
+                const RbPair& pr = pairs[m];
+                float* dst = m < 2 ? PQ[m] : ACC;
+                const int mode = m < 2 ? ACC_STORE : acc_mode;
+                if (fc && fc->npair == 1) {
+                    rc = launch_fused_rb(*fc, pairs, m, 1, krb, c.resblock_dilations[j], cur, dst, bs, rpf_out, mode,
+                                         (float)c.num_kernels, lengths, B, Tmax, stream, prof);
+                    if (rc == MV_OK) {
+                        cur = dst;
+                        continue;
+                    }
+                    if (rc != MV_EUNSUPPORTED) return rc;
+                }
                 LaunchArgs a;
                 a.lengths = lengths;
                 a.B = B;
@@ -335,16 +436,11 @@ static int hifigan_forward(HifiganHandle* h, const float* mel, const int32_t* le
                 SrcBind s2{T1, bs, Cp, rpf_out, 0.1f};
                 a.resid = cur;
                 a.resid_batch_stride = bs;
-                if (m < 2) {
-                    a.out[0].ptr = PQ[m];
-                } else {
-                    a.out[0].ptr = ACC;
-                    a.div = (float)c.num_kernels;
-                    a.out[0].mode = j == 0 ? ACC_STORE : (j == c.num_kernels - 1 ? ACC_ADD_DIV : ACC_ADD);
-                    if (c.num_kernels == 1) a.out[0].mode = ACC_STORE;
-                }
+                a.out[0].ptr = dst;
+                a.out[0].mode = mode;
+                a.div = (float)c.num_kernels;
                 if ((rc = launch_layer(pr.c2, &s2, 1, a, stream, prof))) return rc;
-                cur = PQ[m & 1];
+                cur = dst;
             }
         }
         cur_in = ACC;
@@ -396,6 +492,7 @@ int mv_hifigan_create(const mv_hifigan_cfg* cfg, const mv_tensor* weights, int n
     }
     int rc = init_kernel_attributes();
     if (rc) return rc;
+    if ((rc = init_fused_attributes())) return rc;
     WeightMap W;
     if ((rc = W.load(weights, n_weights))) return rc;
     HifiganHandle* h = new HifiganHandle();
