@@ -130,26 +130,68 @@ __device__ __forceinline__ void stage_tile(char* smem, const ConvPass& cp, const
     }
 }
 
-// One K step: every N tile's B fragment (LDS) against the TM resident A fragments.
-template <bool BF16, int TM, int TN>
-__device__ __forceinline__ void mma_step(f32x4 (&acc)[TM][TN], const u32x4 (&a)[TM], const char* bp, int RS) {
+// B-fragment pipeline: N tiles are consumed in groups of G; while the MFMAs of group g run, the
+// ds_read_b128 of group g+1 (or of the next K step's group 0) are already in flight, so one wave
+// per SIMD keeps the matrix pipe busy without relying on other waves to hide the LDS latency.
+template <int TM, int TN>
+struct BPipe {
+    static constexpr int G = (8 + TM - 1) / TM < TN ? (8 + TM - 1) / TM : TN;  // >= 8 MFMAs per group
+    static constexpr int NG = (TN + G - 1) / G;
+};
+
+template <int TN, int G>
+__device__ __forceinline__ void load_bgroup(u32x4 (&q)[G], const char* bp, int RS, int g) {
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        const u32x4 b = *(const u32x4*)(bp + tn * 16 * RS);
+    for (int j = 0; j < G; ++j)
+        if (g * G + j < TN) q[j] = *(const u32x4*)(bp + (g * G + j) * 16 * RS);
+}
+
+// One K step.  PAR = which of the two buffers holds this step's group 0 on entry; on exit the next
+// step's group 0 (read through bp_next) sits in buffer (PAR + NG) & 1.
+template <bool BF16, int TM, int TN, int PAR>
+__device__ __forceinline__ void mma_step(f32x4 (&acc)[TM][TN], const u32x4 (&a)[TM], const char* bp,
+                                         const char* bp_next, int RS, u32x4 (&q0)[BPipe<TM, TN>::G],
+                                         u32x4 (&q1)[BPipe<TM, TN>::G]) {
+    constexpr int G = BPipe<TM, TN>::G, NG = BPipe<TM, TN>::NG;
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) mma16<BF16>(acc[tm][tn], a[tm], b);
+    for (int g = 0; g < NG; ++g) {
+        const bool cur0 = ((g + PAR) & 1) == 0;
+        if (g + 1 < NG) {
+            if (cur0)
+                load_bgroup<TN, G>(q1, bp, RS, g + 1);
+            else
+                load_bgroup<TN, G>(q0, bp, RS, g + 1);
+        } else {
+            if (cur0)
+                load_bgroup<TN, G>(q1, bp_next, RS, 0);
+            else
+                load_bgroup<TN, G>(q0, bp_next, RS, 0);
+        }
+        // pin the order: hipcc otherwise sinks every ds_read to just before its MFMA (lgkmcnt(0)
+        // after each read), which exposes the full LDS latency at one wave per SIMD
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            if (g * G + j < TN) {
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) mma16<BF16>(acc[tm][g * G + j], a[tm], cur0 ? q0[j] : q1[j]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-// One pass of the K loop: S = ktaps * nkc steps; A fragments stream from global two steps ahead.
-// The loop body is branch-free (prefetch indices are clamped, not guarded) so the accumulators stay
-// in place in the register file.
+// One pass of the K loop: S = ktaps * nkc steps; A fragments stream from global two steps ahead, B
+// fragments from LDS one group ahead.  The loop body is branch-free (prefetch indices are clamped,
+// not guarded) so the accumulators stay in place in the register file.
 template <bool BF16, int TM, int TN>
 __device__ __forceinline__ void mma_pass(f32x4 (&acc)[TM][TN], const char* lds_b, int RS, int ktaps, int dil, int nkc,
                                          const u32x4* wlane, long long mtile_stride) {
+    constexpr int G = BPipe<TM, TN>::G, NG = BPipe<TM, TN>::NG;
     const int S = ktaps * nkc;
     const int tap_wrap = dil * RS - nkc * 64;
     u32x4 a0[TM], a1[TM];
+    u32x4 q0[G], q1[G];
     const int s1 = S > 1 ? 1 : 0;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
@@ -158,32 +200,35 @@ __device__ __forceinline__ void mma_pass(f32x4 (&acc)[TM][TN], const char* lds_b
     }
     int kc = 0;
     const char* bp = lds_b;  // advances 64 B per k-chunk, wraps to the next tap
+    load_bgroup<TN, G>(q0, bp, RS, 0);
+    auto next_bp = [&](const char* cur) {
+        const char* n = cur + 64;
+        if (++kc == nkc) {
+            kc = 0;
+            n += tap_wrap;
+        }
+        return n;
+    };
     int s = 0;
     for (; s + 2 <= S; s += 2) {
-        mma_step<BF16, TM, TN>(acc, a0, bp, RS);
+        const char* bp1 = next_bp(bp);
+        mma_step<BF16, TM, TN, 0>(acc, a0, bp, bp1, RS, q0, q1);
         {
             const int sn = s + 2 < S ? s + 2 : S - 1;
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) a0[tm] = wlane[tm * mtile_stride + (long long)sn * 64];
         }
-        bp += 64;
-        if (++kc == nkc) {
-            kc = 0;
-            bp += tap_wrap;
-        }
-        mma_step<BF16, TM, TN>(acc, a1, bp, RS);
+        // the step after next only exists if s + 2 < S; otherwise re-read this one (harmless)
+        const char* bp2 = s + 2 < S ? next_bp(bp1) : bp1;
+        mma_step<BF16, TM, TN, (NG & 1)>(acc, a1, bp1, bp2, RS, q0, q1);
         {
             const int sn = s + 3 < S ? s + 3 : S - 1;
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) a1[tm] = wlane[tm * mtile_stride + (long long)sn * 64];
         }
-        bp += 64;
-        if (++kc == nkc) {
-            kc = 0;
-            bp += tap_wrap;
-        }
+        bp = bp2;
     }
-    if (s < S) mma_step<BF16, TM, TN>(acc, a0, bp, RS);
+    if (s < S) mma_step<BF16, TM, TN, 0>(acc, a0, bp, bp, RS, q0, q1);
 }
 
 __device__ __forceinline__ void store_out(const ConvOut& o, int b, long long e, long long valid, f32x4 v,
