@@ -96,37 +96,53 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
 }
 
 // Stage rows [row0, row0+rows) x channels [cin_off, cin_off+cb) of one sequence into LDS.
+// Loads are issued U units at a time before any is consumed, so a block that is alone on its CU
+// pays the HBM latency once per batch instead of once per 16-byte unit.
 template <bool BF16, int NTHREADS>
 __device__ __forceinline__ void stage_tile(char* smem, const ConvPass& cp, const float* src_b, int row0, int rows,
                                            int len_rows, int RS) {
     constexpr int UC = BF16 ? 8 : 4;  // channels per 16-byte LDS unit
+    constexpr int U = 8;              // units in flight per thread
     const int upr = cp.cb / UC;
     const int total = rows * upr;
     const float slope = cp.slope;
-    for (int idx = threadIdx.x; idx < total; idx += NTHREADS) {
-        const int r = idx / upr;
-        const int u = idx - r * upr;
-        const int in_row = row0 + r;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (in_row >= 0 && in_row < len_rows) {
-            const float* g = src_b + (long long)in_row * cp.row_stride + cp.cin_off + u * UC;
-            if constexpr (BF16) {
-                const f32x4 x0 = *(const f32x4*)g;
-                const f32x4 x1 = *(const f32x4*)(g + 4);
-                v[0] = pack_bf16(lrelu(x0[0], slope), lrelu(x0[1], slope));
-                v[1] = pack_bf16(lrelu(x0[2], slope), lrelu(x0[3], slope));
-                v[2] = pack_bf16(lrelu(x1[0], slope), lrelu(x1[1], slope));
-                v[3] = pack_bf16(lrelu(x1[2], slope), lrelu(x1[3], slope));
-            } else {
-                f32x4 x0 = *(const f32x4*)g;
-                x0[0] = lrelu(x0[0], slope);
-                x0[1] = lrelu(x0[1], slope);
-                x0[2] = lrelu(x0[2], slope);
-                x0[3] = lrelu(x0[3], slope);
-                v = __builtin_bit_cast(u32x4, x0);
+    for (int base = threadIdx.x; base < total; base += NTHREADS * U) {
+        f32x4 x0[U], x1[BF16 ? U : 1];
+        int dst[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int idx = base + k * NTHREADS;
+            const int r = idx / upr;
+            const int u = idx - r * upr;
+            const int in_row = row0 + r;
+            dst[k] = idx < total ? r * RS + u * 16 : -1;
+            x0[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (BF16) x1[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (idx < total && in_row >= 0 && in_row < len_rows) {
+                const float* g = src_b + (long long)in_row * cp.row_stride + cp.cin_off + u * UC;
+                x0[k] = *(const f32x4*)g;
+                if constexpr (BF16) x1[k] = *(const f32x4*)(g + 4);
             }
         }
-        *(u32x4*)(smem + r * RS + u * 16) = v;
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            if (dst[k] < 0) continue;
+            u32x4 v;
+            if constexpr (BF16) {
+                v[0] = pack_bf16(lrelu(x0[k][0], slope), lrelu(x0[k][1], slope));
+                v[1] = pack_bf16(lrelu(x0[k][2], slope), lrelu(x0[k][3], slope));
+                v[2] = pack_bf16(lrelu(x1[k][0], slope), lrelu(x1[k][1], slope));
+                v[3] = pack_bf16(lrelu(x1[k][2], slope), lrelu(x1[k][3], slope));
+            } else {
+                f32x4 y = x0[k];
+                y[0] = lrelu(y[0], slope);
+                y[1] = lrelu(y[1], slope);
+                y[2] = lrelu(y[2], slope);
+                y[3] = lrelu(y[3], slope);
+                v = __builtin_bit_cast(u32x4, y);
+            }
+            *(u32x4*)(smem + dst[k]) = v;
+        }
     }
 }
 

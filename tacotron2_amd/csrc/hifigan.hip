@@ -28,20 +28,42 @@ struct FusedCfg {
 };
 //                         C   WM WN TN  XREG
 static const FusedCfg kFused[] = {
+    // 8 waves (two per SIMD): the second wave hides LDS / L2 latency and the epilogue phases
+    {32, 768, 512, 3, fused_rb_kernel<32, 1, 8, 6, true>, "fused_rb_kernel<C32,WM1,WN8,TN6,xreg>"},
+    {64, 320, 512, 3, fused_rb_kernel<64, 2, 4, 5, true>, "fused_rb_kernel<C64,WM2,WN4,TN5,xreg>"},
+    {128, 224, 512, 3, fused_rb_kernel<128, 4, 2, 7, true>, "fused_rb_kernel<C128,WM4,WN2,TN7,xreg>"},
+    {256, 112, 512, 1, fused_rb_kernel<256, 8, 1, 7, true>, "fused_rb_kernel<C256,WM8,WN1,TN7,xreg>"},
+    // 4-wave variants, kept for A/B runs (MV_FUSE bit mask: 2 -> C32, 4 -> C64, 8 -> C128)
     {32, 768, 256, 3, fused_rb_kernel<32, 1, 4, 12, true>, "fused_rb_kernel<C32,WM1,WN4,TN12,xreg>"},
     {64, 320, 256, 3, fused_rb_kernel<64, 2, 2, 10, true>, "fused_rb_kernel<C64,WM2,WN2,TN10,xreg>"},
     {128, 240, 256, 1, fused_rb_kernel<128, 4, 1, 15, false>, "fused_rb_kernel<C128,WM4,WN1,TN15,pair>"},
 };
 
+static int env_or(const char* name, int dflt) {
+    const char* s = getenv(name);
+    return s && *s ? atoi(s) : dflt;
+}
+
 static const FusedCfg* fused_cfg_for(int Cp) {
-    static const int enabled = [] {
-        const char* s = getenv("MV_FUSE");
-        return s && *s ? atoi(s) : 1;
-    }();
-    if (!enabled) return nullptr;
-    for (const FusedCfg& f : kFused)
-        if (f.C == Cp) return &f;
+    static const int mode = env_or("MV_FUSE", 1);
+    if (!mode) return nullptr;
+    for (const FusedCfg& f : kFused) {
+        if (f.C != Cp) continue;
+        const bool want4 = (mode & (Cp == 32 ? 2 : Cp == 64 ? 4 : Cp == 128 ? 8 : 0)) != 0;
+        if (Cp == 256 && (mode & 16)) return nullptr;
+        if ((f.threads == 256) == want4) return &f;
+    }
     return nullptr;
+}
+
+// A whole ResBlock (3 pairs) in one launch pays for itself while the halo it recomputes stays small
+// next to the window; past that the pairs run as three launches.
+static bool fuse_whole(const FusedCfg& fc, int K, const int* dils) {
+    if (fc.npair < 3) return false;
+    int H = 0;
+    for (int m = 0; m < 3; ++m) H += (K - 1) / 2 * (dils[m] + 1);
+    static const int pct = env_or("MV_WHOLE_MIN_PCT", 55);  // NT / W at least this
+    return (fc.W - 2 * H) * 100 >= fc.W * pct;
 }
 
 int init_fused_attributes() {
@@ -342,10 +364,15 @@ static int launch_fused_rb(const FusedCfg& fc, const RbPair* pairs, int m0, int 
     p.guardY = pad2;
     const int RS = fc.C * 2 + kLdsRowPad;
     const size_t lds = (size_t)(2 * fc.W + 2 * gA + 2 * pad2) * RS;
-    if (p.NT < 16 || lds > 160 * 1024) return MV_EUNSUPPORTED;
+    static const int pair_pct = env_or("MV_PAIR_MIN_PCT", 60);  // below this the halo recompute costs too much
+    if (p.NT < 16 || lds > 160 * 1024 || p.NT * 100 < fc.W * pair_pct) return MV_EUNSUPPORTED;
     const long long rows = (long long)Tmax * rpf;
     dim3 grid((unsigned)((rows + p.NT - 1) / p.NT), (unsigned)B);
-    if (prof) prof->begin(stream, fc.name, macs * rpf);
+    if (prof) {
+        char nm[128];
+        snprintf(nm, sizeof nm, "%s k=%d", fc.name, K);
+        prof->begin(stream, nm, macs * rpf);
+    }
     hipLaunchKernelGGL(fc.k, grid, dim3(fc.threads), lds, stream, p);
     if (prof) prof->end(stream);
     MV_HIP(hipGetLastError());
@@ -406,7 +433,7 @@ static int hifigan_forward(HifiganHandle* h, const float* mel, const int32_t* le
             const int acc_mode =
                 c.num_kernels == 1 || j == 0 ? ACC_STORE : (j == c.num_kernels - 1 ? ACC_ADD_DIV : ACC_ADD);
             const int krb = c.resblock_kernel_sizes[j];
-            if (fc && fc->npair == 3) {
+            if (fc && fuse_whole(*fc, krb, c.resblock_dilations[j])) {
                 rc = launch_fused_rb(*fc, pairs, 0, 3, krb, c.resblock_dilations[j], A, ACC, bs, rpf_out, acc_mode,
                                      (float)c.num_kernels, lengths, B, Tmax, stream, prof);
                 if (rc == MV_OK) continue;
@@ -416,7 +443,7 @@ static int hifigan_forward(HifiganHandle* h, const float* mel, const int32_t* le
                 const RbPair& pr = pairs[m];
                 float* dst = m < 2 ? PQ[m] : ACC;
                 const int mode = m < 2 ? ACC_STORE : acc_mode;
-                if (fc && fc->npair == 1) {
+                if (fc) {
                     rc = launch_fused_rb(*fc, pairs, m, 1, krb, c.resblock_dilations[j], cur, dst, bs, rpf_out, mode,
                                          (float)c.num_kernels, lengths, B, Tmax, stream, prof);
                     if (rc == MV_OK) {

@@ -37,7 +37,7 @@ static int env_int(const char* name, int dflt) {
 }
 
 static int default_cfg(int M) {
-    if (M % 256 == 0) return env_int("MV_CFG_M256", 1);
+    if (M % 256 == 0) return env_int("MV_CFG_M256", 0);
     if (M % 128 == 0) return env_int("MV_CFG_M128", 2);
     if (M % 64 == 0) return env_int("MV_CFG_M64", 3);
     return env_int("MV_CFG_M32", 4);
