@@ -1,0 +1,172 @@
+"""Length-bucketed, utterance-sharded batch vocoding (the do_syn.py outer loop, do_syn.py:235-394,
+re-shaped for 1-8 MI355X).
+
+The reference vocodes one chunk at a time on one GPU (do_syn.py:188-189,302-394).  Chunks are
+independent, so the path shards with no data-path collective: utterances are sorted by frame
+count, cut into buckets of similar length (the kernels mask every layer at each sequence's own
+end, so a bucket is ONE length-masked call), and the buckets are dealt to ranks
+longest-processing-time-first on their frame totals.  Each rank is one process with one GPU and
+its own replica of the weights; `torch.distributed` (RCCL on GPUs, gloo in the CPU tests) is used
+only after the work, to gather a fixed-size statistics record per rank.
+"""
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import synth
+
+
+@dataclass
+class Bucket:
+    indices: list            # utterance indices, longest first
+    lengths: list            # frames per utterance
+    cost: int = 0            # sum of frames (the arithmetic is proportional to it)
+
+    @property
+    def tmax(self):
+        return max(self.lengths)
+
+
+def make_buckets(lengths, max_batch=32, width=64, max_frames=32 * 1024):
+    """Sort by length (longest first) and cut into buckets: at most `max_batch` utterances, at most
+    `width` frames between the longest and the shortest, at most `max_frames` padded frames
+    (B * Tmax, which bounds the workspace).  Zero-length utterances get no bucket."""
+    order = sorted((i for i in range(len(lengths)) if lengths[i] > 0), key=lambda i: (-int(lengths[i]), i))
+    buckets, cur = [], None
+    for i in order:
+        T = int(lengths[i])
+        if cur is not None:
+            tmax = cur.lengths[0]
+            if len(cur.indices) >= max_batch or tmax - T > width or tmax * (len(cur.indices) + 1) > max_frames:
+                buckets.append(cur)
+                cur = None
+        if cur is None:
+            cur = Bucket([], [])
+        cur.indices.append(i)
+        cur.lengths.append(T)
+        cur.cost += T
+    if cur is not None:
+        buckets.append(cur)
+    return buckets
+
+
+def shard_buckets(buckets, world):
+    """Longest-processing-time-first: heaviest bucket to the least loaded rank.  Deterministic, so
+    every rank computes the same assignment without communicating."""
+    loads = [0] * world
+    shards = [[] for _ in range(world)]
+    for bi in sorted(range(len(buckets)), key=lambda b: (-buckets[b].cost, b)):
+        r = min(range(world), key=lambda k: (loads[k], k))
+        shards[r].append(bi)
+        loads[r] += buckets[bi].cost
+    return shards, loads
+
+
+def pad_bucket(mels, bucket, pad_value=synth.MEL_PAD_VALUE, device=None):
+    """Right-pad the bucket's mels ([80,T] tensors / arrays) to [B,80,Tmax] plus an int32 length vector."""
+    B, tmax = len(bucket.indices), bucket.tmax
+    n_mels = int(mels[bucket.indices[0]].shape[0])
+    x = torch.full((B, n_mels, tmax), float(pad_value), dtype=torch.float32)
+    for b, (i, T) in enumerate(zip(bucket.indices, bucket.lengths)):
+        x[b, :, :T] = torch.as_tensor(mels[i], dtype=torch.float32)[:, :T]
+    lengths = torch.tensor(bucket.lengths, dtype=torch.int32)
+    if device is not None:
+        x, lengths = x.to(device), lengths.to(device)
+    return x, lengths
+
+
+@dataclass
+class ShardStats:
+    rank: int = 0
+    utterances: int = 0
+    frames: int = 0
+    audio_seconds: float = 0.0
+    wall_seconds: float = 0.0
+    calls: int = 0
+    checksum: float = 0.0  # sum |pcm| over the shard: a cheap whole-corpus fingerprint
+    per_rank: list = field(default_factory=list)
+
+    def as_tensor(self):
+        return torch.tensor([self.rank, self.utterances, self.frames, self.audio_seconds, self.wall_seconds,
+                             self.calls, self.checksum, 0.0], dtype=torch.float64)
+
+    @staticmethod
+    def from_tensor(t):
+        v = t.tolist()
+        return ShardStats(int(v[0]), int(v[1]), int(v[2]), v[3], v[4], int(v[5]), v[6])
+
+
+def synthesize_shard(vocoder, mels, lengths=None, rank=0, world=1, device=None, fe_wav=22050, hop=256,
+                     max_batch=32, width=64, max_frames=32 * 1024, keep_audio=True, out="pcm16"):
+    """Vocode this rank's share of `mels` (list of [80,T]).  Returns ({utterance index: int16 / float
+    numpy waveform}, ShardStats).  `vocoder(mel[B,80,T], lengths=int32[B], out=...) -> [B, hop*T]`."""
+    if lengths is None:
+        lengths = [int(m.shape[1]) for m in mels]
+    buckets = make_buckets(lengths, max_batch, width, max_frames)
+    shards, _ = shard_buckets(buckets, world)
+    stats = ShardStats(rank=rank)
+    results = {}
+    sync = torch.cuda.synchronize if (device is not None and torch.device(device).type == "cuda") else (lambda: None)
+    sync()
+    t0 = time.perf_counter()
+    for bi in shards[rank]:
+        bk = buckets[bi]
+        x, lens = pad_bucket(mels, bk, device=device)
+        wav = vocoder(x, lengths=lens, out=out)
+        stats.calls += 1
+        host = wav.cpu().numpy()  # the D->H copy is part of the driver's work (do_syn.py:393)
+        for b, (i, T) in enumerate(zip(bk.indices, bk.lengths)):
+            a = host[b, : T * hop]
+            stats.checksum += float(np.abs(a.astype(np.float64)).sum())
+            if keep_audio:
+                results[i] = a.copy()
+        stats.utterances += len(bk.indices)
+        stats.frames += bk.cost
+    sync()
+    stats.wall_seconds = time.perf_counter() - t0
+    stats.audio_seconds = stats.frames * hop / float(fe_wav)
+    return results, stats
+
+
+def gather_stats(stats: ShardStats, device=None):
+    """One fixed-size all_gather per rank AFTER the work (the path's only collective)."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        total = ShardStats(**{k: getattr(stats, k) for k in ("rank", "utterances", "frames", "audio_seconds",
+                                                              "wall_seconds", "calls", "checksum")})
+        total.per_rank = [stats]
+        return total
+    t = stats.as_tensor()
+    if device is not None and dist.get_backend() == "nccl":
+        t = t.to(device)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    per = [ShardStats.from_tensor(o.cpu()) for o in out]
+    total = ShardStats(rank=-1)
+    total.per_rank = per
+    total.utterances = sum(p.utterances for p in per)
+    total.frames = sum(p.frames for p in per)
+    total.audio_seconds = sum(p.audio_seconds for p in per)
+    total.wall_seconds = max(p.wall_seconds for p in per)  # the job ends with its slowest rank
+    total.calls = sum(p.calls for p in per)
+    total.checksum = sum(p.checksum for p in per)
+    return total
+
+
+def synthetic_corpus(n, seed=1234, lo=86, hi=430):
+    """Config 4 of BASELINE.json: n utterance lengths of 2-10 s; mels are generated lazily per index."""
+    lengths = synth.synthetic_lengths(n, seed, lo, hi)
+
+    class _Lazy:
+        def __len__(self):
+            return n
+
+        def __getitem__(self, i):
+            return synth.synthetic_mel(int(lengths[i]), seed * 100003 + i)
+
+    return _Lazy(), [int(t) for t in lengths]

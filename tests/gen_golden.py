@@ -162,6 +162,51 @@ def waveglow_case(name, cfg, seed, T, B, mel_seed, noise_seed, sigma):
     print(name, "wav rms %.4f" % float(audio.pow(2).mean().sqrt()), "max %.3f" % float(audio.abs().max()))
 
 
+def waveglow_pickle_case(name):
+    """A tiny WaveGlow saved the way waveglow/train.py:54-62 saves it (the whole module, weight-norm
+    hooks still on, under 'model') plus the walk of infer() on it: pins D1's pickled-module load."""
+    import copy as _copy
+
+    from glow import WaveGlow
+
+    cfg = {"n_mel_channels": 8, "n_flows": 4, "n_group": 8, "n_early_every": 2, "n_early_size": 2,
+           "WN_config": {"n_layers": 2, "n_channels": 32, "kernel_size": 3}}
+    st = synth.waveglow_state(cfg, 5)
+    m = WaveGlow(**cfg)
+    sd = m.state_dict()
+    for k, v in st.items():
+        t = torch.from_numpy(v)
+        if k in sd:
+            sd[k] = t
+        else:  # weight-normalised: weight_v = w, weight_g = ||w|| per output channel
+            sd[k + "_v"] = t
+            sd[k + "_g"] = t.flatten(1).norm(dim=1).view(-1, 1, 1)
+    m.load_state_dict(sd)
+    torch.save({"model": m, "iteration": 1, "learning_rate": 1e-4}, os.path.join(GOLD, name + ".pt"))
+    ref = WaveGlow.remove_weightnorm(_copy.deepcopy(m)).eval()
+    T, sigma = 6, 0.6
+    mel = synth.synthetic_mel(T, 21, n_mels=8)[None]
+    noise = synth.waveglow_noise(cfg, 1, T, 22)
+    spect = ref.upsample(torch.from_numpy(mel))[:, :, :-(1024 - 256)]
+    spect = spect.unfold(2, 8, 8).permute(0, 2, 1, 3)
+    spect = spect.contiguous().view(spect.size(0), spect.size(1), -1).permute(0, 2, 1)
+    audio = sigma * torch.from_numpy(noise[0])
+    ni = 1
+    for k in reversed(range(ref.n_flows)):
+        n_half = int(audio.size(1) / 2)
+        a0, a1 = audio[:, :n_half, :], audio[:, n_half:, :]
+        out = ref.WN[k]((a0, spect))
+        a1 = (a1 - out[:, :n_half, :]) / torch.exp(out[:, n_half:, :])
+        audio = ref.convinv[k](torch.cat([a0, a1], 1), reverse=True)
+        if k % ref.n_early_every == 0 and k > 0:
+            audio = torch.cat((sigma * torch.from_numpy(noise[ni]), audio), 1)
+            ni += 1
+    wav = audio.permute(0, 2, 1).contiguous().view(1, -1).numpy()
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), wav=wav, T=np.int32(T), sigma=np.float32(sigma),
+                        mel_seed=np.int32(21), noise_seed=np.int32(22), cfg=json.dumps(cfg))
+    print(name, "wav rms %.4f" % float(np.sqrt((wav ** 2).mean())))
+
+
 def pcm_case(name):
     """D2: 32768*y -> astype('int16') exactly as do_syn.py:389-394 executes it (numpy on host)."""
     d = np.load(os.path.join(GOLD, "hifigan_v1_T64.npz"))
@@ -190,6 +235,7 @@ def main():
     wg256["WN_config"]["n_channels"] = 256  # the repo's own waveglow/config.json:37 width
     waveglow_case("waveglow_c256_T64", wg256, 0, 64, 1, 1234, 1234, 0.666)
     pcm_case("pcm16_v1_T64")
+    waveglow_pickle_case("waveglow_tiny_ref")
 
 
 if __name__ == "__main__":
