@@ -209,4 +209,224 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// fused_stage_kernel: ALL ResBlocks of one MRF stage plus their mean (models.py:154-160) in one
+// launch, and -- for the last stage -- the final leaky_relu(0.01) -> conv_post -> tanh
+// (models.py:161-163) as well, so the largest activation of the network is read once and never
+// written.  Same window scheme as fused_rb_kernel; every ResBlock restarts from the stage input x
+// (re-read from L2 into registers) and the running sum of their outputs stays in registers.
+// The window halo is that of the widest ResBlock (k = 11: 60 rows a side).
+struct FusedStageParams {
+    const float* x;  // [B][rows][C]
+    float* out;      // [B][rows][C] mean of the ResBlocks (unused when post_w is set)
+    long long batch_stride;
+    const int32_t* lengths;
+    int Tmax;
+    int rows_per_frame;
+    int nrb;
+    int K[3];
+    int dil[3][3];
+    const void* w1[3][3];
+    const void* w2[3][3];
+    const float* b1[3][3];
+    const float* b2[3][3];
+    float div;
+    int NT;      // rows written per block
+    int H;       // halo per side (incl. 3 rows for conv_post when fused)
+    int guardA;
+    int guardY;
+    // fused conv_post (last stage): weights [7][C] fp32, bias [1]; output [B][Tmax*rows_per_frame]
+    const float* post_w;
+    const float* post_b;
+    void* wav;
+    int wav_pcm16;
+};
+
+template <int C, int WM, int WN, int TN>
+__global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedStageParams p) {
+    constexpr int TM = C / 16 / WM;
+    constexpr int W = 16 * TN * WN;
+    constexpr int NTHREADS = WM * WN * 64;
+    constexpr int RS = C * 2 + kLdsRowPad;
+    constexpr int NKC = C / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int b = blockIdx.y;
+    const int len = (p.lengths ? p.lengths[b] : p.Tmax) * p.rows_per_frame;
+    const int out0 = blockIdx.x * p.NT;
+    const long long Lmax = (long long)p.Tmax * p.rows_per_frame;
+    if (out0 >= len) {
+        // the waveform past a sequence's end is defined to be zero
+        if (p.post_w) {
+            for (int i = threadIdx.x; i < p.NT; i += NTHREADS) {
+                const long long t = (long long)out0 + i;
+                if (t >= Lmax) break;
+                if (p.wav_pcm16)
+                    ((int16_t*)p.wav)[b * Lmax + t] = 0;
+                else
+                    ((float*)p.wav)[b * Lmax + t] = 0.f;
+            }
+        }
+        return;
+    }
+    const int t0 = out0 - p.H;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int lr = lane & 15, lg = lane >> 4;
+
+    char* A16 = smem;
+    char* Y16 = smem + (W + 2 * p.guardA) * RS;
+    const float* xb = p.x + (long long)b * p.batch_stride;
+    {
+        const int upr = RS / 16;
+        for (int idx = threadIdx.x; idx < 2 * p.guardA * upr; idx += NTHREADS) {
+            const int r = idx / upr, u = idx - r * upr;
+            const int row = r < p.guardA ? r : W + r;
+            *(u32x4*)(A16 + row * RS + u * 16) = u32x4{0u, 0u, 0u, 0u};
+        }
+        for (int idx = threadIdx.x; idx < 2 * p.guardY * upr; idx += NTHREADS) {
+            const int r = idx / upr, u = idx - r * upr;
+            const int row = r < p.guardY ? r : W + r;
+            *(u32x4*)(Y16 + row * RS + u * 16) = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    char* A0 = A16 + p.guardA * RS;
+    char* Y0 = Y16 + p.guardY * RS;
+
+    f32x4 X[TM][TN], SUM[TM][TN], acc[TM][TN];
+    for (int j = 0; j < p.nrb; ++j) {
+        const int K = p.K[j];
+        const long long mtile_stride = (long long)K * NKC * 64;
+        const long long woff = (long long)(wm * TM) * mtile_stride + lane;
+        const int pad2 = (K - 1) / 2;
+        if (j > 0) __syncthreads();  // every wave is done reading A16 / Y16 of the previous ResBlock
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int n = (wn * TN + tn) * 16 + lr;
+            const int g = t0 + n;
+            const bool in_seq = g >= 0 && g < len;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int ch = (wm * TM + tm) * 16 + lg * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (in_seq) v = *(const f32x4*)(xb + (long long)g * C + ch);
+                X[tm][tn] = v;
+                *(unsigned long long*)(A0 + n * RS + ch * 2) = pack4_bf16_lrelu(v, 0.1f, in_seq);
+            }
+        }
+        for (int m = 0; m < 3; ++m) {
+            const int d = p.dil[j][m];
+            const int pad1 = d * (K - 1) / 2;
+            __syncthreads();
+            conv_window<TM, TN>(acc, A0 + ((wn * TN * 16 + lr) - pad1) * RS + lg * 16, RS, K, d, NKC,
+                                (const u32x4*)p.w1[j][m] + woff, mtile_stride);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int ch = (wm * TM + tm) * 16 + lg * 4;
+                const f32x4 bias = *(const f32x4*)(p.b1[j][m] + ch);
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const int n = (wn * TN + tn) * 16 + lr;
+                    const int g = t0 + n;
+                    *(unsigned long long*)(Y0 + n * RS + ch * 2) =
+                        pack4_bf16_lrelu(acc[tm][tn] + bias, 0.1f, g >= 0 && g < len);
+                }
+            }
+            __syncthreads();
+            conv_window<TM, TN>(acc, Y0 + ((wn * TN * 16 + lr) - pad2) * RS + lg * 16, RS, K, 1, NKC,
+                                (const u32x4*)p.w2[j][m] + woff, mtile_stride);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int ch = (wm * TM + tm) * 16 + lg * 4;
+                const f32x4 bias = *(const f32x4*)(p.b2[j][m] + ch);
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const int n = (wn * TN + tn) * 16 + lr;
+                    const int g = t0 + n;
+                    X[tm][tn] = (acc[tm][tn] + bias) + X[tm][tn];
+                    if (m < 2)
+                        *(unsigned long long*)(A0 + n * RS + ch * 2) =
+                            pack4_bf16_lrelu(X[tm][tn], 0.1f, g >= 0 && g < len);
+                }
+            }
+        }
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) SUM[tm][tn] = j == 0 ? X[tm][tn] : SUM[tm][tn] + X[tm][tn];
+    }
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) SUM[tm][tn][i] = SUM[tm][tn][i] / p.div;
+
+    if (!p.post_w) {
+        float* ob = p.out + (long long)b * p.batch_stride;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int ch = (wm * TM + tm) * 16 + lg * 4;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int n = (wn * TN + tn) * 16 + lr;
+                const int g = t0 + n;
+                if (n < p.H || n >= p.H + p.NT || g >= len) continue;
+                *(f32x4*)(ob + (long long)g * C + ch) = SUM[tm][tn];
+            }
+        }
+        return;
+    }
+
+    // ---- fused conv_post: M[n][c] = lrelu(mean, 0.01) (zero outside the sequence) as fp32 in LDS,
+    //      then one output sample per thread: tanh(b + sum_k sum_c w[k][c] * M[n+k-3][c])
+    __syncthreads();  // all waves are done with A16 / Y16
+    float* M = (float*)smem;  // [W][C] fp32 = W*C*4 bytes <= the two bf16 tiles
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int ch = (wm * TM + tm) * 16 + lg * 4;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int n = (wn * TN + tn) * 16 + lr;
+            const int g = t0 + n;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (g >= 0 && g < len) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = lrelu(SUM[tm][tn][i], 0.01f);
+            }
+            *(f32x4*)(M + n * C + ch) = v;
+        }
+    }
+    __syncthreads();
+    const float bias = p.post_b[0];
+    for (int i = threadIdx.x; i < p.NT; i += NTHREADS) {
+        const int n = p.H + i;
+        const long long t = (long long)out0 + i;
+        if (t >= Lmax) break;
+        float y = 0.f;
+        if (t < len) {
+            float a = bias;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                const f32x4* mr = (const f32x4*)(M + (n + k - 3) * C);
+                const f32x4* wr = (const f32x4*)(p.post_w + k * C);
+#pragma unroll
+                for (int c = 0; c < C / 4; ++c) {
+                    const f32x4 v = mr[c], q = wr[c];
+                    a += v[0] * q[0];
+                    a += v[1] * q[1];
+                    a += v[2] * q[2];
+                    a += v[3] * q[3];
+                }
+            }
+            y = tanhf(a);
+        }
+        if (p.wav_pcm16)
+            ((int16_t*)p.wav)[b * Lmax + t] = (int16_t)(int32_t)(32768.0f * y);
+        else
+            ((float*)p.wav)[b * Lmax + t] = y;
+    }
+}
+
 }  // namespace mv

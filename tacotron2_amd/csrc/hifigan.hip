@@ -66,8 +66,28 @@ static bool fuse_whole(const FusedCfg& fc, int K, const int* dils) {
     return (fc.W - 2 * H) * 100 >= fc.W * pct;
 }
 
+// whole-stage launches (all ResBlocks + MRF mean [+ conv_post]) for the HBM-bound low-channel stages
+typedef void (*StageKernel)(const FusedStageParams);
+struct StageCfg {
+    int C, W, threads;
+    StageKernel k;
+    const char* name;
+};
+static const StageCfg kStage[] = {
+    {32, 768, 512, fused_stage_kernel<32, 1, 8, 6>, "fused_stage_kernel<C32,WM1,WN8,TN6>"},
+    {64, 384, 512, fused_stage_kernel<64, 2, 4, 6>, "fused_stage_kernel<C64,WM2,WN4,TN6>"},
+};
+static const StageCfg* stage_cfg_for(int Cp) {
+    static const int mode = env_or("MV_STAGE", 3);  // bit 0: C32, bit 1: C64
+    for (const StageCfg& f : kStage)
+        if (f.C == Cp && (mode & (Cp == 32 ? 1 : 2))) return &f;
+    return nullptr;
+}
+
 int init_fused_attributes() {
     for (const FusedCfg& f : kFused)
+        MV_HIP(hipFuncSetAttribute((const void*)f.k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    for (const StageCfg& f : kStage)
         MV_HIP(hipFuncSetAttribute((const void*)f.k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return MV_OK;
 }
@@ -379,6 +399,70 @@ static int launch_fused_rb(const FusedCfg& fc, const RbPair* pairs, int m0, int 
     return MV_OK;
 }
 
+// All ResBlocks of stage `i` (+ conv_post when `wav` is given) in one launch.
+static int launch_fused_stage(const StageCfg& sc, const HifiganHandle* h, int i, const float* x, float* out,
+                              long long bs, int rpf, void* wav, int out_format, const int32_t* lengths, int B, int Tmax,
+                              hipStream_t stream, Profiler* prof) {
+    const mv_hifigan_cfg& c = h->cfg;
+    if (c.num_kernels > 3) return MV_EUNSUPPORTED;
+    FusedStageParams p;
+    memset(&p, 0, sizeof p);
+    p.x = x;
+    p.out = out;
+    p.batch_stride = bs;
+    p.lengths = lengths;
+    p.Tmax = Tmax;
+    p.rows_per_frame = rpf;
+    p.nrb = c.num_kernels;
+    p.div = (float)c.num_kernels;
+    int H = 0, gA = 0, gY = 0;
+    double macs = 0;
+    for (int j = 0; j < c.num_kernels; ++j) {
+        const int K = c.resblock_kernel_sizes[j];
+        const int pad2 = (K - 1) / 2;
+        p.K[j] = K;
+        int Hj = 0;
+        for (int m = 0; m < 3; ++m) {
+            const RbPair& pr = h->rb[((size_t)i * c.num_kernels + j) * 3 + m];
+            if (pr.c1.npass != 1 || pr.c2.npass != 1) return MV_EUNSUPPORTED;
+            const int d = c.resblock_dilations[j][m];
+            p.dil[j][m] = d;
+            p.w1[j][m] = pr.c1.w;
+            p.w2[j][m] = pr.c2.w;
+            p.b1[j][m] = pr.c1.bias;
+            p.b2[j][m] = pr.c2.bias;
+            Hj += pad2 * (d + 1);
+            gA = std::max(gA, d * pad2);
+            macs += pr.c1.alg_macs_per_n + pr.c2.alg_macs_per_n;
+        }
+        H = std::max(H, Hj);
+        gY = std::max(gY, pad2);
+    }
+    if (wav) {
+        H += 3;
+        p.post_w = h->post_w;
+        p.post_b = h->post_b;
+        p.wav = wav;
+        p.wav_pcm16 = out_format == MV_OUT_PCM16;
+        macs += (double)h->C[h->nstage] * 7;
+    }
+    p.H = H;
+    p.NT = sc.W - 2 * H;
+    p.guardA = gA;
+    p.guardY = gY;
+    const int RS = sc.C * 2 + kLdsRowPad;
+    const size_t lds = (size_t)(2 * sc.W + 2 * gA + 2 * gY) * RS;
+    static const int min_pct = env_or("MV_STAGE_MIN_PCT", 55);
+    if (lds > 160 * 1024 || p.NT * 100 < sc.W * min_pct) return MV_EUNSUPPORTED;
+    const long long rows = (long long)Tmax * rpf;
+    dim3 grid((unsigned)((rows + p.NT - 1) / p.NT), (unsigned)B);
+    if (prof) prof->begin(stream, wav ? std::string(sc.name) + "+conv_post" : std::string(sc.name), macs * rpf);
+    hipLaunchKernelGGL(sc.k, grid, dim3(sc.threads), lds, stream, p);
+    if (prof) prof->end(stream);
+    MV_HIP(hipGetLastError());
+    return MV_OK;
+}
+
 static int hifigan_forward(HifiganHandle* h, const float* mel, const int32_t* lengths, int B, int Tmax, void* wav,
                            int out_format, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     const mv_hifigan_cfg& c = h->cfg;
@@ -412,6 +496,7 @@ static int hifigan_forward(HifiganHandle* h, const float* mel, const int32_t* le
     const float* cur_in = PRE;  // input of the next upsampling
     int rpf = 1;                // rows per mel frame of cur_in
     int acc_idx = 1;            // buf[acc_idx] receives the MRF mean of this stage
+    bool post_done = false;     // conv_post already fused into the last stage's launch
     for (int i = 0; i < h->nstage; ++i) {
         const int u = c.upsample_rates[i], K = c.upsample_kernel_sizes[i];
         const int Cin_p = h->Cp[i], Cp = h->Cp[i + 1];
@@ -427,6 +512,20 @@ static int hifigan_forward(HifiganHandle* h, const float* mel, const int32_t* le
                                Tmax, stream, prof)))
             return rc;
         const FusedCfg* fc = h->precision == MV_PREC_BF16 ? fused_cfg_for(Cp) : nullptr;
+        const StageCfg* sc = h->precision == MV_PREC_BF16 ? stage_cfg_for(Cp) : nullptr;
+        if (sc) {
+            const bool last = i == h->nstage - 1;
+            rc = launch_fused_stage(*sc, h, i, A, ACC, bs, rpf_out, last ? wav : nullptr, out_format, lengths, B, Tmax,
+                                    stream, prof);
+            if (rc == MV_OK) {
+                cur_in = ACC;
+                rpf = rpf_out;
+                acc_idx = (acc_idx + 2) % 5;
+                post_done = last;
+                continue;
+            }
+            if (rc != MV_EUNSUPPORTED) return rc;
+        }
         for (int j = 0; j < c.num_kernels; ++j) {
             const float* cur = A;
             const RbPair* pairs = &h->rb[((size_t)i * c.num_kernels + j) * 3];
@@ -474,7 +573,7 @@ static int hifigan_forward(HifiganHandle* h, const float* mel, const int32_t* le
         rpf = rpf_out;
         acc_idx = (acc_idx + 2) % 5;
     }
-    {
+    if (!post_done) {
         const int Clp = h->Cp[h->nstage];
         const long long L = (long long)Tmax * rpf;
         dim3 grid((unsigned)((L + 255) / 256), (unsigned)B);
