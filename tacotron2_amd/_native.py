@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmelvoc.so")
+LIB_PATH = os.environ.get("MELVOC_LIB") or os.path.join(_HERE, "libmelvoc.so")  # MELVOC_LIB: diagnostic builds
 
 PREC_FP32, PREC_BF16 = 0, 1
 OUT_F32, OUT_PCM16 = 0, 1

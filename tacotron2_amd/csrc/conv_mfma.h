@@ -75,6 +75,11 @@ struct ConvParams {
 
 template <bool BF16>
 __device__ __forceinline__ void mma16(f32x4& acc, const u32x4& a, const u32x4& b) {
+#if defined(MV_ABLATE) && MV_ABLATE >= 1
+    // timing-only build (tools/ablate.sh): keep the operands live, issue no MFMA
+    asm volatile("" ::"v"(a), "v"(b));
+    return;
+#endif
     if constexpr (BF16) {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
                                                       acc, 0, 0, 0);
@@ -159,7 +164,13 @@ template <int TN, int G>
 __device__ __forceinline__ void load_bgroup(u32x4 (&q)[G], const char* bp, int RS, int g) {
 #pragma unroll
     for (int j = 0; j < G; ++j)
-        if (g * G + j < TN) q[j] = *(const u32x4*)(bp + (g * G + j) * 16 * RS);
+        if (g * G + j < TN) {
+#if defined(MV_ABLATE) && MV_ABLATE >= 2
+            q[j] = u32x4{(unsigned)(size_t)bp, 0u, 0u, 0u};  // timing-only build: no LDS read
+#else
+            q[j] = *(const u32x4*)(bp + (g * G + j) * 16 * RS);
+#endif
+        }
 }
 
 // One K step.  PAR = which of the two buffers holds this step's group 0 on entry; on exit the next
@@ -197,23 +208,28 @@ __device__ __forceinline__ void mma_step(f32x4 (&acc)[TM][TN], const u32x4 (&a)[
     }
 }
 
-// One pass of the K loop: S = ktaps * nkc steps; A fragments stream from global two steps ahead, B
-// fragments from LDS one group ahead.  The loop body is branch-free (prefetch indices are clamped,
-// not guarded) so the accumulators stay in place in the register file.
+// One pass of the K loop: S = ktaps * nkc steps.  A fragments stream L2 -> registers FOUR steps
+// ahead (a wave keeps 4*TM KiB in flight: with two steps the weight stream, not the matrix pipe,
+// paced the loop), B fragments come from LDS one group ahead.  The loop body is branch-free
+// (prefetch indices are clamped, not guarded) so the accumulators stay in place.
 template <bool BF16, int TM, int TN>
 __device__ __forceinline__ void mma_pass(f32x4 (&acc)[TM][TN], const char* lds_b, int RS, int ktaps, int dil, int nkc,
                                          const u32x4* wlane, long long mtile_stride) {
     constexpr int G = BPipe<TM, TN>::G, NG = BPipe<TM, TN>::NG;
+    constexpr int P1 = NG & 1;  // buffer parity of the 2nd / 4th step of an unrolled group
     const int S = ktaps * nkc;
     const int tap_wrap = dil * RS - nkc * 64;
-    u32x4 a0[TM], a1[TM];
+    u32x4 a0[TM], a1[TM], a2[TM], a3[TM];
     u32x4 q0[G], q1[G];
-    const int s1 = S > 1 ? 1 : 0;
+    auto fetch = [&](u32x4 (&a)[TM], int step) {
+        const int sn = step < S ? step : S - 1;
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-        a0[tm] = wlane[tm * mtile_stride];
-        a1[tm] = wlane[tm * mtile_stride + s1 * 64];
-    }
+        for (int tm = 0; tm < TM; ++tm) a[tm] = wlane[tm * mtile_stride + (long long)sn * 64];
+    };
+    fetch(a0, 0);
+    fetch(a1, 1);
+    fetch(a2, 2);
+    fetch(a3, 3);
     int kc = 0;
     const char* bp = lds_b;  // advances 64 B per k-chunk, wraps to the next tap
     load_bgroup<TN, G>(q0, bp, RS, 0);
@@ -226,25 +242,31 @@ __device__ __forceinline__ void mma_pass(f32x4 (&acc)[TM][TN], const char* lds_b
         return n;
     };
     int s = 0;
-    for (; s + 2 <= S; s += 2) {
+    for (; s + 4 <= S; s += 4) {
         const char* bp1 = next_bp(bp);
         mma_step<BF16, TM, TN, 0>(acc, a0, bp, bp1, RS, q0, q1);
-        {
-            const int sn = s + 2 < S ? s + 2 : S - 1;
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm) a0[tm] = wlane[tm * mtile_stride + (long long)sn * 64];
-        }
-        // the step after next only exists if s + 2 < S; otherwise re-read this one (harmless)
-        const char* bp2 = s + 2 < S ? next_bp(bp1) : bp1;
-        mma_step<BF16, TM, TN, (NG & 1)>(acc, a1, bp1, bp2, RS, q0, q1);
-        {
-            const int sn = s + 3 < S ? s + 3 : S - 1;
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm) a1[tm] = wlane[tm * mtile_stride + (long long)sn * 64];
-        }
-        bp = bp2;
+        fetch(a0, s + 4);
+        const char* bp2 = next_bp(bp1);
+        mma_step<BF16, TM, TN, P1>(acc, a1, bp1, bp2, RS, q0, q1);
+        fetch(a1, s + 5);
+        const char* bp3 = next_bp(bp2);
+        mma_step<BF16, TM, TN, 0>(acc, a2, bp2, bp3, RS, q0, q1);
+        fetch(a2, s + 6);
+        // past the last step there is nothing to read ahead: re-read this one (harmless)
+        const char* bp4 = s + 4 < S ? next_bp(bp3) : bp3;
+        mma_step<BF16, TM, TN, P1>(acc, a3, bp3, bp4, RS, q0, q1);
+        fetch(a3, s + 7);
+        bp = bp4;
     }
-    if (s < S) mma_step<BF16, TM, TN, 0>(acc, a0, bp, bp, RS, q0, q1);
+    if (s < S) {
+        const char* bp1 = s + 1 < S ? next_bp(bp) : bp;
+        mma_step<BF16, TM, TN, 0>(acc, a0, bp, bp1, RS, q0, q1);
+        if (s + 1 < S) {
+            const char* bp2 = s + 2 < S ? next_bp(bp1) : bp1;
+            mma_step<BF16, TM, TN, P1>(acc, a1, bp1, bp2, RS, q0, q1);
+            if (s + 2 < S) mma_step<BF16, TM, TN, 0>(acc, a2, bp2, bp2, RS, q0, q1);
+        }
+    }
 }
 
 __device__ __forceinline__ void store_out(const ConvOut& o, int b, long long e, long long valid, f32x4 v,
