@@ -7,9 +7,9 @@ int build_conv1d_layer(Layer* L, const HostTensor* w, const HostTensor* b, int C
                        int cin_pad, int cout_pad, bool bf16, int force_cfg);
 int build_convT_layer(Layer* L, const HostTensor* w, const HostTensor* b, int Cin, int Cout, int K, int u, int cin_pad,
                       int cout_pad, bool bf16, int force_cfg);
-int launch_convT(const Layer& L, const float* x, long long x_bs, int cin_stride, int rows_per_frame, float slope,
-                 float* y, long long y_bs, int cout_pad, int K, int u, int pad, const int32_t* lengths, int B,
-                 int Tmax, hipStream_t stream, Profiler* prof);
+int launch_convT(const Layer& L, const void* x, long long x_bs, int cin_stride, int rows_per_frame, float slope,
+                 void* y, long long y_bs, int cout_pad, int K, int u, int pad, const int32_t* lengths, int B,
+                 int Tmax, hipStream_t stream, Profiler* prof, int in_f16, int out_f16);
 }  // namespace mv
 
 using namespace mv;
@@ -134,7 +134,7 @@ int mv_test_conv_transpose1d(const float* x, const int32_t* lengths, int B, int 
                            test_cfg());
     if (rc) return rc;
     rc = launch_convT(Lr, x, (long long)L * Cin, Cin, 1, pre_slope, y, (long long)L * stride * Cout, Cout, K, stride,
-                      padding, lengths, B, L, (hipStream_t)stream, nullptr);
+                      padding, lengths, B, L, (hipStream_t)stream, nullptr, 0, 0);
     hipError_t e = hipStreamSynchronize((hipStream_t)stream);
     free_layer(&Lr);
     if (rc) return rc;

@@ -91,11 +91,12 @@ int build_layer(Layer* L, const std::vector<SrcSpec>& srcs, int M, const std::ve
 void free_layer(Layer* L);
 
 struct SrcBind {
-    const float* ptr;
+    const void* ptr;
     long long batch_stride;
     int row_stride;
     int rows_per_frame;
     float slope;
+    int f16 = 0;  // tensor holds float16
 };
 
 struct LaunchArgs {
@@ -106,7 +107,7 @@ struct LaunchArgs {
     int n_extra = 0;
     int split = 1 << 30;
     ConvOut out[2] = {};
-    const float* resid = nullptr;
+    const void* resid = nullptr;  // typed like out[0]
     long long resid_batch_stride = 0;
     float div = 1.f;
 };

@@ -28,8 +28,9 @@
 namespace mv {
 
 struct FusedRbParams {
-    const float* x;   // [B][rows][C] fp32
-    float* out;       // same layout
+    const void* x;    // [B][rows][C] float32, or float16 when io16
+    void* out;        // same layout and type
+    int io16;
     long long batch_stride;
     const int32_t* lengths;
     int Tmax;
@@ -87,7 +88,8 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
 
     char* A16 = smem;                                   // rows [-guardA, W + guardA)
     char* Y16 = smem + (W + 2 * p.guardA) * RS;         // rows [-guardY, W + guardY)
-    const float* xb = p.x + (long long)b * p.batch_stride;
+    const void* xb = p.io16 ? (const void*)((const _Float16*)p.x + (long long)b * p.batch_stride)
+                            : (const void*)((const float*)p.x + (long long)b * p.batch_stride);
 
     // zero the guard rows once (they stand for rows outside the window; their values only reach
     // outputs inside the halo, but they must be finite)
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
             for (int tm = 0; tm < TM; ++tm) {
                 const int ch = (wm * TM + tm) * 16 + lg * 4;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (in_seq) v = *(const f32x4*)(xb + (long long)g * C + ch);
+                if (in_seq) v = ld4(xb, (long long)g * C + ch, p.io16);
                 X[tm][tn] = v;
                 *(unsigned long long*)(A0 + n * RS + ch * 2) = pack4_bf16_lrelu(v, 0.1f, in_seq);
             }
@@ -129,6 +131,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
         cp.cin_off = 0;
         cp.cb = C;
         cp.slope = 0.1f;
+        cp.src_f16 = p.io16;
         stage_tile<true, NTHREADS>(A0, cp, xb, t0, W, len, RS);
     }
 
@@ -178,7 +181,8 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
     }
 
     // ---- store the rows the halo has not reached, with the MRF accumulation of models.py:154-160
-    float* ob = p.out + (long long)b * p.batch_stride;
+    void* ob = p.io16 ? (void*)((_Float16*)p.out + (long long)b * p.batch_stride)
+                      : (void*)((float*)p.out + (long long)b * p.batch_stride);
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         const int ch = (wm * TM + tm) * 16 + lg * 4;
@@ -194,17 +198,17 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
             if constexpr (XREG)
                 v = X[tm][tn];
             else
-                v = (acc[tm][tn] + bias2) + *(const f32x4*)(xb + e);
+                v = (acc[tm][tn] + bias2) + ld4(xb, e, p.io16);
             if (p.mode == ACC_ADD) {
-                v += *(const f32x4*)(ob + e);
+                v += ld4(ob, e, p.io16);
             } else if (p.mode == ACC_ADD_DIV) {
-                v += *(const f32x4*)(ob + e);
+                v += ld4(ob, e, p.io16);
                 v[0] = v[0] / p.div;
                 v[1] = v[1] / p.div;
                 v[2] = v[2] / p.div;
                 v[3] = v[3] / p.div;
             }
-            *(f32x4*)(ob + e) = v;
+            st4(ob, e, v, p.io16);
         }
     }
 }
@@ -217,8 +221,9 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
 // (re-read from L2 into registers) and the running sum of their outputs stays in registers.
 // The window halo is that of the widest ResBlock (k = 11: 60 rows a side).
 struct FusedStageParams {
-    const float* x;  // [B][rows][C]
-    float* out;      // [B][rows][C] mean of the ResBlocks (unused when post_w is set)
+    const void* x;   // [B][rows][C] float32, or float16 when io16
+    void* out;       // [B][rows][C] mean of the ResBlocks, same type (unused when post_w is set)
+    int io16;
     long long batch_stride;
     const int32_t* lengths;
     int Tmax;
@@ -277,7 +282,8 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
 
     char* A16 = smem;
     char* Y16 = smem + (W + 2 * p.guardA) * RS;
-    const float* xb = p.x + (long long)b * p.batch_stride;
+    const void* xb = p.io16 ? (const void*)((const _Float16*)p.x + (long long)b * p.batch_stride)
+                            : (const void*)((const float*)p.x + (long long)b * p.batch_stride);
     {
         const int upr = RS / 16;
         for (int idx = threadIdx.x; idx < 2 * p.guardA * upr; idx += NTHREADS) {
@@ -310,7 +316,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
             for (int tm = 0; tm < TM; ++tm) {
                 const int ch = (wm * TM + tm) * 16 + lg * 4;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (in_seq) v = *(const f32x4*)(xb + (long long)g * C + ch);
+                if (in_seq) v = ld4(xb, (long long)g * C + ch, p.io16);
                 X[tm][tn] = v;
                 *(unsigned long long*)(A0 + n * RS + ch * 2) = pack4_bf16_lrelu(v, 0.1f, in_seq);
             }
@@ -364,7 +370,8 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
             for (int i = 0; i < 4; ++i) SUM[tm][tn][i] = SUM[tm][tn][i] / p.div;
 
     if (!p.post_w) {
-        float* ob = p.out + (long long)b * p.batch_stride;
+        void* ob = p.io16 ? (void*)((_Float16*)p.out + (long long)b * p.batch_stride)
+                          : (void*)((float*)p.out + (long long)b * p.batch_stride);
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
             const int ch = (wm * TM + tm) * 16 + lg * 4;
@@ -373,7 +380,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
                 const int n = (wn * TN + tn) * 16 + lr;
                 const int g = t0 + n;
                 if (n < p.H || n >= p.H + p.NT || g >= len) continue;
-                *(f32x4*)(ob + (long long)g * C + ch) = SUM[tm][tn];
+                st4(ob, (long long)g * C + ch, SUM[tm][tn], p.io16);
             }
         }
         return;

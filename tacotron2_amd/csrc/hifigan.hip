@@ -142,7 +142,7 @@ struct HifiganHandle : mv_handle_s {
 
 // ---- conv_post: lrelu(slope) -> Conv1d(C -> 1, k=7, pad=3) -> tanh -> f32 or PCM16 -----------
 template <bool PCM>
-__global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict__ x, long long batch_stride, int Cp,
+__global__ __launch_bounds__(256) void conv_post_kernel(const void* __restrict__ x, int x_f16, long long batch_stride, int Cp,
                                                         const float* __restrict__ w, const float* __restrict__ bias,
                                                         const int32_t* __restrict__ lengths, int Tmax, int hop,
                                                         float slope, void* __restrict__ out) {
@@ -157,15 +157,14 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict_
     const long long len = (long long)(lengths ? lengths[b] : Tmax) * hop;
     float y = 0.f;
     if (t < len) {
-        const float* xb = x + (long long)b * batch_stride;
+        const long long xoff = (long long)b * batch_stride;
         float acc = bias[0];
         for (int k = 0; k < 7; ++k) {
             const long long r = t + k - 3;
             if (r < 0 || r >= len) continue;
-            const f32x4* xr = (const f32x4*)(xb + r * Cp);
             const f32x4* wr = (const f32x4*)(ws + k * Cp);
             for (int c = 0; c < Cp / 4; ++c) {
-                const f32x4 v = xr[c], q = wr[c];
+                const f32x4 v = ld4(x, xoff + r * Cp + c * 4, x_f16), q = wr[c];
                 acc += lrelu(v[0], slope) * q[0];
                 acc += lrelu(v[1], slope) * q[1];
                 acc += lrelu(v[2], slope) * q[2];
@@ -238,11 +237,11 @@ int build_convT_layer(Layer* L, const HostTensor* w, const HostTensor* b, int Ci
 }
 
 // Launch a transposed-conv layer built by build_convT_layer.
-int launch_convT(const Layer& L, const float* x, long long x_bs, int cin_stride, int rows_per_frame, float slope,
-                 float* y, long long y_bs, int cout_pad, int K, int u, int pad, const int32_t* lengths, int B,
-                 int Tmax, hipStream_t stream, Profiler* prof) {
+int launch_convT(const Layer& L, const void* x, long long x_bs, int cin_stride, int rows_per_frame, float slope,
+                 void* y, long long y_bs, int cout_pad, int K, int u, int pad, const int32_t* lengths, int B,
+                 int Tmax, hipStream_t stream, Profiler* prof, int in_f16, int out_f16) {
     const int J = (K + u - 1) / u;
-    SrcBind sb{x, x_bs, cin_stride, rows_per_frame, slope};
+    SrcBind sb{x, x_bs, cin_stride, rows_per_frame, slope, in_f16};
     LaunchArgs a;
     a.lengths = lengths;
     a.B = B;
@@ -255,6 +254,7 @@ int launch_convT(const Layer& L, const float* x, long long x_bs, int cin_stride,
     a.out[0].off = -(long long)pad * cout_pad;
     a.out[0].valid_per_frame = (long long)rows_per_frame * u * cout_pad;
     a.out[0].mode = ACC_STORE;
+    a.out[0].f16 = out_f16;
     return launch_layer(L, &sb, 1, a, stream, prof);
 }
 
@@ -349,12 +349,13 @@ static int hifigan_build(HifiganHandle* h, WeightMap& W) {
 
 // Runs pairs [m0, m0+npair) of one ResBlock fused; returns MV_EUNSUPPORTED if the window is too small.
 static int launch_fused_rb(const FusedCfg& fc, const RbPair* pairs, int m0, int npair, int K, const int* dils,
-                           const float* x, float* out, long long bs, int rpf, int mode, float div,
-                           const int32_t* lengths, int B, int Tmax, hipStream_t stream, Profiler* prof) {
+                           const void* x, void* out, long long bs, int rpf, int mode, float div,
+                           const int32_t* lengths, int B, int Tmax, hipStream_t stream, Profiler* prof, int io16) {
     FusedRbParams p;
     memset(&p, 0, sizeof p);
     p.x = x;
     p.out = out;
+    p.io16 = io16;
     p.batch_stride = bs;
     p.lengths = lengths;
     p.Tmax = Tmax;
@@ -400,15 +401,16 @@ static int launch_fused_rb(const FusedCfg& fc, const RbPair* pairs, int m0, int 
 }
 
 // All ResBlocks of stage `i` (+ conv_post when `wav` is given) in one launch.
-static int launch_fused_stage(const StageCfg& sc, const HifiganHandle* h, int i, const float* x, float* out,
+static int launch_fused_stage(const StageCfg& sc, const HifiganHandle* h, int i, const void* x, void* out,
                               long long bs, int rpf, void* wav, int out_format, const int32_t* lengths, int B, int Tmax,
-                              hipStream_t stream, Profiler* prof) {
+                              hipStream_t stream, Profiler* prof, int io16) {
     const mv_hifigan_cfg& c = h->cfg;
     if (c.num_kernels > 3) return MV_EUNSUPPORTED;
     FusedStageParams p;
     memset(&p, 0, sizeof p);
     p.x = x;
     p.out = out;
+    p.io16 = io16;
     p.batch_stride = bs;
     p.lengths = lengths;
     p.Tmax = Tmax;
@@ -473,6 +475,9 @@ static int hifigan_forward(HifiganHandle* h, const float* mel, const int32_t* le
     }
     int rc;
     Profiler* prof = h->prof.on ? &h->prof : nullptr;
+    // bf16 mode: activations between kernels are float16 (see ld4/st4 in conv_mfma.h); fp32 mode: float32
+    static const int io16_env = env_or("MV_IO16", 1);
+    const int io16 = h->precision == MV_PREC_BF16 ? io16_env : 0;
     const size_t bt = (size_t)B * Tmax;
     char* ws = (char*)workspace;
     float* X0 = (float*)ws;
@@ -490,7 +495,7 @@ static int hifigan_forward(HifiganHandle* h, const float* mel, const int32_t* le
         a.lengths = lengths;
         a.B = B;
         a.Tmax = Tmax;
-        a.out[0] = ConvOut{PRE, (long long)Tmax * h->Cp[0], 0, h->Cp[0], h->Cp[0], ACC_STORE};
+        a.out[0] = ConvOut{PRE, (long long)Tmax * h->Cp[0], 0, h->Cp[0], h->Cp[0], ACC_STORE, io16};
         if ((rc = launch_layer(h->pre, &sb, 1, a, stream, prof))) return rc;
     }
     const float* cur_in = PRE;  // input of the next upsampling
@@ -509,14 +514,14 @@ static int hifigan_forward(HifiganHandle* h, const float* mel, const int32_t* le
         const long long bs_in = (long long)Tmax * rpf * Cin_p;
         const long long bs = (long long)Tmax * rpf_out * Cp;
         if ((rc = launch_convT(h->ups[i], cur_in, bs_in, Cin_p, rpf, 0.1f, A, bs, Cp, K, u, (K - u) / 2, lengths, B,
-                               Tmax, stream, prof)))
+                               Tmax, stream, prof, io16, io16)))
             return rc;
         const FusedCfg* fc = h->precision == MV_PREC_BF16 ? fused_cfg_for(Cp) : nullptr;
         const StageCfg* sc = h->precision == MV_PREC_BF16 ? stage_cfg_for(Cp) : nullptr;
         if (sc) {
             const bool last = i == h->nstage - 1;
             rc = launch_fused_stage(*sc, h, i, A, ACC, bs, rpf_out, last ? wav : nullptr, out_format, lengths, B, Tmax,
-                                    stream, prof);
+                                    stream, prof, io16);
             if (rc == MV_OK) {
                 cur_in = ACC;
                 rpf = rpf_out;
@@ -534,7 +539,7 @@ static int hifigan_forward(HifiganHandle* h, const float* mel, const int32_t* le
             const int krb = c.resblock_kernel_sizes[j];
             if (fc && fuse_whole(*fc, krb, c.resblock_dilations[j])) {
                 rc = launch_fused_rb(*fc, pairs, 0, 3, krb, c.resblock_dilations[j], A, ACC, bs, rpf_out, acc_mode,
-                                     (float)c.num_kernels, lengths, B, Tmax, stream, prof);
+                                     (float)c.num_kernels, lengths, B, Tmax, stream, prof, io16);
                 if (rc == MV_OK) continue;
                 if (rc != MV_EUNSUPPORTED) return rc;
             }
@@ -544,7 +549,7 @@ static int hifigan_forward(HifiganHandle* h, const float* mel, const int32_t* le
                 const int mode = m < 2 ? ACC_STORE : acc_mode;
                 if (fc) {
                     rc = launch_fused_rb(*fc, pairs, m, 1, krb, c.resblock_dilations[j], cur, dst, bs, rpf_out, mode,
-                                         (float)c.num_kernels, lengths, B, Tmax, stream, prof);
+                                         (float)c.num_kernels, lengths, B, Tmax, stream, prof, io16);
                     if (rc == MV_OK) {
                         cur = dst;
                         continue;
@@ -556,10 +561,10 @@ static int hifigan_forward(HifiganHandle* h, const float* mel, const int32_t* le
                 a.B = B;
                 a.Tmax = Tmax;
                 a.n_rows_per_frame = rpf_out;
-                a.out[0] = ConvOut{T1, bs, 0, (long long)rpf_out * Cp, Cp, ACC_STORE};
-                SrcBind s1{cur, bs, Cp, rpf_out, 0.1f};
+                a.out[0] = ConvOut{T1, bs, 0, (long long)rpf_out * Cp, Cp, ACC_STORE, io16};
+                SrcBind s1{cur, bs, Cp, rpf_out, 0.1f, io16};
                 if ((rc = launch_layer(pr.c1, &s1, 1, a, stream, prof))) return rc;
-                SrcBind s2{T1, bs, Cp, rpf_out, 0.1f};
+                SrcBind s2{T1, bs, Cp, rpf_out, 0.1f, io16};
                 a.resid = cur;
                 a.resid_batch_stride = bs;
                 a.out[0].ptr = dst;
@@ -579,10 +584,10 @@ static int hifigan_forward(HifiganHandle* h, const float* mel, const int32_t* le
         dim3 grid((unsigned)((L + 255) / 256), (unsigned)B);
         const size_t lds = (size_t)7 * Clp * 4;
         if (out_format == MV_OUT_PCM16)
-            hipLaunchKernelGGL(conv_post_kernel<true>, grid, dim3(256), lds, stream, cur_in, L * Clp, Clp, h->post_w,
+            hipLaunchKernelGGL(conv_post_kernel<true>, grid, dim3(256), lds, stream, (const void*)cur_in, io16, L * Clp, Clp, h->post_w,
                                h->post_b, lengths, Tmax, rpf, 0.01f, wav);
         else
-            hipLaunchKernelGGL(conv_post_kernel<false>, grid, dim3(256), lds, stream, cur_in, L * Clp, Clp, h->post_w,
+            hipLaunchKernelGGL(conv_post_kernel<false>, grid, dim3(256), lds, stream, (const void*)cur_in, io16, L * Clp, Clp, h->post_w,
                                h->post_b, lengths, Tmax, rpf, 0.01f, wav);
         MV_HIP(hipGetLastError());
     }

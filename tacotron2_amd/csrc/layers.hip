@@ -263,6 +263,7 @@ int launch_layer(const Layer& L, const SrcBind* srcs, int nsrc, const LaunchArgs
         cp.pad_left = lp.pad_left;
         cp.rows_per_frame = s.rows_per_frame;
         cp.slope = s.slope;
+        cp.src_f16 = s.f16;
     }
     p.w = L.w;
     p.steps_total = L.steps_total;

@@ -5,7 +5,7 @@
 set -e
 cd "$(dirname "$0")/../tacotron2_amd/csrc"
 mkdir -p ../../diag
-for lvl in 1 2; do
+for lvl in 1 2 3 4; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -mllvm -amdgpu-mfma-vgpr-form=1 \
      -DMV_ABLATE=$lvl -shared -o ../../diag/libmelvoc_ab$lvl.so layers.hip small_kernels.hip hifigan.hip waveglow.hip api.hip
 done
