@@ -27,6 +27,55 @@
 
 namespace mv {
 
+// MV_TRACE (diagnostic builds only, tools/trace.sh): thread 0 of every block accumulates shader-clock time
+// per phase category and appends one record to a global table that tools/trace_report.py aggregates.
+enum { TR_SETUP = 0, TR_LOADX, TR_BARRIER, TR_KLOOP, TR_EPI, TR_STORE, TR_POST, TR_NCAT };
+#ifdef MV_TRACE
+constexpr int kTraceSlots = 16;
+constexpr int kTraceCap = 1 << 19;
+__device__ unsigned long long g_trace[(size_t)kTraceCap * kTraceSlots];
+__device__ unsigned int g_trace_n;
+struct Tracer {
+    unsigned long long* t;  // TR_NCAT accumulators in LDS, touched by thread 0 only
+    unsigned long long last, first;
+    __device__ __forceinline__ void begin() {
+        if (threadIdx.x == 0) {
+            for (int i = 0; i < TR_NCAT; ++i) t[i] = 0;
+            first = last = clock64();
+        }
+    }
+    __device__ __forceinline__ void lap(int cat) {
+        if (threadIdx.x == 0) {
+            const unsigned long long now = clock64();
+            t[cat] += now - last;
+            last = now;
+        }
+    }
+    __device__ __forceinline__ void flush(int tag) {
+        if (threadIdx.x != 0) return;
+        const unsigned slot = atomicAdd(&g_trace_n, 1u);
+        if (slot >= (unsigned)kTraceCap) return;
+        unsigned long long* r = g_trace + (size_t)slot * kTraceSlots;
+        r[0] = (unsigned long long)tag;
+        r[1] = wall_clock64();
+        r[2] = first;
+        r[3] = last;
+        for (int i = 0; i < TR_NCAT; ++i) r[4 + i] = t[i];
+    }
+};
+#define MV_TRACER(tr)                                    \
+    __shared__ unsigned long long tr##_lds[TR_NCAT];     \
+    Tracer tr;                                           \
+    tr.t = tr##_lds;                                     \
+    tr.begin()
+#define MV_LAP(tr, cat) (tr).lap(cat)
+#define MV_FLUSH(tr, tag) (tr).flush(tag)
+#else
+#define MV_TRACER(tr) ((void)0)
+#define MV_LAP(tr, cat) ((void)0)
+#define MV_FLUSH(tr, tag) ((void)0)
+#endif
+
 struct FusedRbParams {
     const void* x;    // [B][rows][C] float32, or float16 when io16
     void* out;        // same layout and type
@@ -80,6 +129,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
     const int len = (p.lengths ? p.lengths[b] : p.Tmax) * p.rows_per_frame;
     const int out0 = blockIdx.x * p.NT;  // first row this block writes
     if (out0 >= len) return;
+    MV_TRACER(tr);
     const int t0 = out0 - p.H;           // global row of window row 0
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -143,9 +193,12 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
     for (int m = 0; m < p.npair; ++m) {
         const int d = p.dil[m];
         const int pad1 = d * (p.K - 1) / 2;
+        MV_LAP(tr, m == 0 ? TR_LOADX : TR_EPI);
         __syncthreads();  // A16 complete
+        MV_LAP(tr, TR_BARRIER);
         conv_window<TM, TN>(acc, A0 + ((wn * TN * 16 + lr) - pad1) * RS + lg * 16, RS, p.K, d, NKC,
                             (const u32x4*)p.w1[m] + woff, mtile_stride);
+        MV_LAP(tr, TR_KLOOP);
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
             const int ch = (wm * TM + tm) * 16 + lg * 4;
@@ -158,9 +211,12 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
                     pack4_bf16_lrelu(acc[tm][tn] + bias, 0.1f, g >= 0 && g < len);
             }
         }
+        MV_LAP(tr, TR_EPI);
         __syncthreads();  // Y16 complete, A16 free
+        MV_LAP(tr, TR_BARRIER);
         conv_window<TM, TN>(acc, Y0 + ((wn * TN * 16 + lr) - pad2) * RS + lg * 16, RS, p.K, 1, NKC,
                             (const u32x4*)p.w2[m] + woff, mtile_stride);
+        MV_LAP(tr, TR_KLOOP);
         if constexpr (XREG) {
             const bool more = m + 1 < p.npair;
 #pragma unroll
@@ -180,6 +236,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
         }
     }
 
+    MV_LAP(tr, TR_EPI);
     // ---- store the rows the halo has not reached, with the MRF accumulation of models.py:154-160
     void* ob = p.io16 ? (void*)((_Float16*)p.out + (long long)b * p.batch_stride)
                       : (void*)((float*)p.out + (long long)b * p.batch_stride);
@@ -211,6 +268,8 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
             st4(ob, e, v, p.io16);
         }
     }
+    MV_LAP(tr, TR_STORE);
+    MV_FLUSH(tr, (C << 16) | (p.K << 8) | p.npair);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -275,6 +334,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
         return;
     }
     const int t0 = out0 - p.H;
+    MV_TRACER(tr);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave - wm * WN;
@@ -306,7 +366,9 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
         const long long mtile_stride = (long long)K * NKC * 64;
         const long long woff = (long long)(wm * TM) * mtile_stride + lane;
         const int pad2 = (K - 1) / 2;
+        MV_LAP(tr, j == 0 ? TR_SETUP : TR_EPI);
         if (j > 0) __syncthreads();  // every wave is done reading A16 / Y16 of the previous ResBlock
+        MV_LAP(tr, TR_BARRIER);
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             const int n = (wn * TN + tn) * 16 + lr;
@@ -324,9 +386,12 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
         for (int m = 0; m < 3; ++m) {
             const int d = p.dil[j][m];
             const int pad1 = d * (K - 1) / 2;
+            MV_LAP(tr, m == 0 ? TR_LOADX : TR_EPI);
             __syncthreads();
+            MV_LAP(tr, TR_BARRIER);
             conv_window<TM, TN>(acc, A0 + ((wn * TN * 16 + lr) - pad1) * RS + lg * 16, RS, K, d, NKC,
                                 (const u32x4*)p.w1[j][m] + woff, mtile_stride);
+            MV_LAP(tr, TR_KLOOP);
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
                 const int ch = (wm * TM + tm) * 16 + lg * 4;
@@ -339,9 +404,12 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
                         pack4_bf16_lrelu(acc[tm][tn] + bias, 0.1f, g >= 0 && g < len);
                 }
             }
+            MV_LAP(tr, TR_EPI);
             __syncthreads();
+            MV_LAP(tr, TR_BARRIER);
             conv_window<TM, TN>(acc, Y0 + ((wn * TN * 16 + lr) - pad2) * RS + lg * 16, RS, K, 1, NKC,
                                 (const u32x4*)p.w2[j][m] + woff, mtile_stride);
+            MV_LAP(tr, TR_KLOOP);
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
                 const int ch = (wm * TM + tm) * 16 + lg * 4;
@@ -369,6 +437,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
 #pragma unroll
             for (int i = 0; i < 4; ++i) SUM[tm][tn][i] = SUM[tm][tn][i] / p.div;
 
+    MV_LAP(tr, TR_EPI);
     if (!p.post_w) {
         void* ob = p.io16 ? (void*)((_Float16*)p.out + (long long)b * p.batch_stride)
                           : (void*)((float*)p.out + (long long)b * p.batch_stride);
@@ -383,6 +452,8 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
                 st4(ob, (long long)g * C + ch, SUM[tm][tn], p.io16);
             }
         }
+        MV_LAP(tr, TR_STORE);
+        MV_FLUSH(tr, (C << 16) | 0xff00 | p.nrb);
         return;
     }
 
@@ -434,6 +505,8 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
         else
             ((float*)p.wav)[b * Lmax + t] = y;
     }
+    MV_LAP(tr, TR_POST);
+    MV_FLUSH(tr, (C << 16) | 0xfe00 | p.nrb);
 }
 
 }  // namespace mv

@@ -15,6 +15,12 @@
 #include <cmath>
 
 #include "fused_rb.h"
+
+#ifdef MV_TRACE
+static constexpr int kFusedMaxLds = 160 * 1024 - 256;  // the tracer's static LDS comes off the top
+#else
+static constexpr int kFusedMaxLds = 160 * 1024;
+#endif
 #include "handle.h"
 
 namespace mv {
@@ -86,9 +92,9 @@ static const StageCfg* stage_cfg_for(int Cp) {
 
 int init_fused_attributes() {
     for (const FusedCfg& f : kFused)
-        MV_HIP(hipFuncSetAttribute((const void*)f.k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MV_HIP(hipFuncSetAttribute((const void*)f.k, hipFuncAttributeMaxDynamicSharedMemorySize, kFusedMaxLds));
     for (const StageCfg& f : kStage)
-        MV_HIP(hipFuncSetAttribute((const void*)f.k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MV_HIP(hipFuncSetAttribute((const void*)f.k, hipFuncAttributeMaxDynamicSharedMemorySize, kFusedMaxLds));
     return MV_OK;
 }
 
@@ -386,7 +392,7 @@ static int launch_fused_rb(const FusedCfg& fc, const RbPair* pairs, int m0, int 
     const int RS = fc.C * 2 + kLdsRowPad;
     const size_t lds = (size_t)(2 * fc.W + 2 * gA + 2 * pad2) * RS;
     static const int pair_pct = env_or("MV_PAIR_MIN_PCT", 60);  // below this the halo recompute costs too much
-    if (p.NT < 16 || lds > 160 * 1024 || p.NT * 100 < fc.W * pair_pct) return MV_EUNSUPPORTED;
+    if (p.NT < 16 || lds > kFusedMaxLds || p.NT * 100 < fc.W * pair_pct) return MV_EUNSUPPORTED;
     const long long rows = (long long)Tmax * rpf;
     dim3 grid((unsigned)((rows + p.NT - 1) / p.NT), (unsigned)B);
     if (prof) {
@@ -455,7 +461,7 @@ static int launch_fused_stage(const StageCfg& sc, const HifiganHandle* h, int i,
     const int RS = sc.C * 2 + kLdsRowPad;
     const size_t lds = (size_t)(2 * sc.W + 2 * gA + 2 * gY) * RS;
     static const int min_pct = env_or("MV_STAGE_MIN_PCT", 55);
-    if (lds > 160 * 1024 || p.NT * 100 < sc.W * min_pct) return MV_EUNSUPPORTED;
+    if (lds > kFusedMaxLds || p.NT * 100 < sc.W * min_pct) return MV_EUNSUPPORTED;
     const long long rows = (long long)Tmax * rpf;
     dim3 grid((unsigned)((rows + p.NT - 1) / p.NT), (unsigned)B);
     if (prof) prof->begin(stream, wav ? std::string(sc.name) + "+conv_post" : std::string(sc.name), macs * rpf);
@@ -667,3 +673,20 @@ int mv_hifigan_forward(mv_handle hh, const float* mel, const int32_t* lengths, i
 }
 
 }  // extern "C"
+
+#ifdef MV_TRACE
+// Diagnostic builds only (tools/trace.sh): fetch and reset the per-block phase records of fused_rb.h.
+extern "C" __attribute__((visibility("default"))) long long mv_trace_read(unsigned long long* host, long long max_records) {
+    unsigned int n = 0;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(mv::g_trace_n), sizeof(n)) != hipSuccess) return -1;
+    long long take = n < (unsigned)mv::kTraceCap ? n : mv::kTraceCap;
+    if (take > max_records) take = max_records;
+    if (host && take > 0 &&
+        hipMemcpyFromSymbol(host, HIP_SYMBOL(mv::g_trace), (size_t)take * mv::kTraceSlots * 8) != hipSuccess)
+        return -1;
+    const unsigned int zero = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(mv::g_trace_n), &zero, sizeof(zero)) != hipSuccess) return -1;
+    return take;
+}
+#endif
