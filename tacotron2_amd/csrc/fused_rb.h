@@ -109,10 +109,106 @@ __device__ __forceinline__ void conv_window(f32x4 (&acc)[TM][TN], const char* ld
     mma_pass<true, TM, TN>(acc, lds_b, RS, ktaps, dil, nkc, wlane, mtile_stride);
 }
 
+// leaky_relu on 4 values as max(x, slope*x) (0 < slope <= 1): two packed multiplies + four v_max
+__device__ __forceinline__ f32x4 lrelu4(const f32x4& v, float slope) {
+    const f32x4 s = v * slope;
+    return f32x4{fmaxf(v[0], s[0]), fmaxf(v[1], s[1]), fmaxf(v[2], s[2]), fmaxf(v[3], s[3])};
+}
+
+__device__ __forceinline__ unsigned long long pack4_bf16(const f32x4& v) {
+    return ((unsigned long long)pack_bf16(v[2], v[3]) << 32) | pack_bf16(v[0], v[1]);
+}
+
 __device__ __forceinline__ unsigned long long pack4_bf16_lrelu(const f32x4& v, float slope, bool keep) {
-    const unsigned lo = pack_bf16(lrelu(v[0], slope), lrelu(v[1], slope));
-    const unsigned hi = pack_bf16(lrelu(v[2], slope), lrelu(v[3], slope));
-    return keep ? ((unsigned long long)hi << 32) | lo : 0ull;
+    return keep ? pack4_bf16(lrelu4(v, slope)) : 0ull;
+}
+
+__device__ __forceinline__ unsigned long long pack4_f16_sat(const f32x4& v) {
+    f16x4 h;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h[i] = (_Float16)fminf(fmaxf(v[i], -65504.f), 65504.f);
+    return __builtin_bit_cast(unsigned long long, h);
+}
+
+__device__ __forceinline__ f32x4 unpack4_f16(unsigned long long q) {
+    const f16x4 h = __builtin_bit_cast(f16x4, q);
+    return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+}
+
+// Coalesced window load (float16 activations): rows [t0, t0+W) x C channels of one sequence, 16 bytes per
+// lane along the channel axis, every load of a thread issued before the first is consumed.  Each unit is
+// written twice: raw float16 into the Y tile (from where every wave afterwards picks the fragments of its
+// fp32 residual registers) and bf16(lrelu(x)) into the A tile (conv1's B operand).  Rows outside [0, len)
+// are zeros in both.
+template <int C, int W, int NTHREADS>
+__device__ __forceinline__ void load_window16(const _Float16* xb, int t0, int len, char* A0, char* Y0, int RS) {
+    constexpr int UPR = C / 8;
+    constexpr int TOTAL = W * UPR;
+    constexpr int PER = (TOTAL + NTHREADS - 1) / NTHREADS;
+    u32x4 raw[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int idx = threadIdx.x + k * NTHREADS;
+        const int r = idx / UPR, u = idx - r * UPR;
+        const int g = t0 + r;
+        raw[k] = u32x4{0u, 0u, 0u, 0u};
+        if (idx < TOTAL && g >= 0 && g < len) raw[k] = *(const u32x4*)(xb + (long long)g * C + u * 8);
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int idx = threadIdx.x + k * NTHREADS;
+        if (idx >= TOTAL) continue;
+        const int r = idx / UPR, u = idx - r * UPR;
+        const f16x8 h = __builtin_bit_cast(f16x8, raw[k]);
+        const f32x4 lo = lrelu4(f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]}, 0.1f);
+        const f32x4 hi = lrelu4(f32x4{(float)h[4], (float)h[5], (float)h[6], (float)h[7]}, 0.1f);
+        const u32x4 v = {pack_bf16(lo[0], lo[1]), pack_bf16(lo[2], lo[3]), pack_bf16(hi[0], hi[1]),
+                         pack_bf16(hi[2], hi[3])};
+        *(u32x4*)(Y0 + r * RS + u * 16) = raw[k];
+        *(u32x4*)(A0 + r * RS + u * 16) = v;
+    }
+}
+
+// Coalesced window store (float16 activations): rows [H, H+NT) of the float16 tile at T0 (row stride RS)
+// go to rows t0+H.. of the output, 16 bytes per lane, with the MRF accumulation of models.py:154-160.
+template <int C, int NTHREADS>
+__device__ __forceinline__ void store_window16(_Float16* ob, const char* T0, int RS, int t0, int H, int NT, int len,
+                                               int mode, float div) {
+    constexpr int UPR = C / 8;
+    constexpr int U = 4;
+    int rows = len - (t0 + H);
+    rows = rows < NT ? rows : NT;
+    const int total = rows * UPR;
+    for (int base = threadIdx.x; base < total; base += NTHREADS * U) {
+        u32x4 old[U];
+        if (mode != ACC_STORE) {
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const int idx = base + k * NTHREADS;
+                const int r = idx / UPR, u = idx - r * UPR;
+                if (idx < total) old[k] = *(const u32x4*)(ob + (long long)(t0 + H + r) * C + u * 8);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int idx = base + k * NTHREADS;
+            if (idx >= total) continue;
+            const int r = idx / UPR, u = idx - r * UPR;
+            u32x4 v = *(const u32x4*)(T0 + (H + r) * RS + u * 16);
+            if (mode != ACC_STORE) {
+                const f16x8 a = __builtin_bit_cast(f16x8, v), o = __builtin_bit_cast(f16x8, old[k]);
+                f16x8 y;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float t = (float)a[i] + (float)o[i];
+                    if (mode == ACC_ADD_DIV) t = t / div;
+                    y[i] = (_Float16)fminf(fmaxf(t, -65504.f), 65504.f);
+                }
+                v = __builtin_bit_cast(u32x4, y);
+            }
+            *(u32x4*)(ob + (long long)(t0 + H + r) * C + u * 8) = v;
+        }
+    }
 }
 
 template <int C, int WM, int WN, int TN, bool XREG>
@@ -131,6 +227,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
     if (out0 >= len) return;
     MV_TRACER(tr);
     const int t0 = out0 - p.H;           // global row of window row 0
+    const bool interior = t0 >= 0 && t0 + W <= len;  // no row of the window needs masking
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave - wm * WN;
@@ -140,6 +237,8 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
     char* Y16 = smem + (W + 2 * p.guardA) * RS;         // rows [-guardY, W + guardY)
     const void* xb = p.io16 ? (const void*)((const _Float16*)p.x + (long long)b * p.batch_stride)
                             : (const void*)((const float*)p.x + (long long)b * p.batch_stride);
+    void* ob = p.io16 ? (void*)((_Float16*)p.out + (long long)b * p.batch_stride)
+                      : (void*)((float*)p.out + (long long)b * p.batch_stride);
 
     // zero the guard rows once (they stand for rows outside the window; their values only reach
     // outputs inside the halo, but they must be finite)
@@ -159,21 +258,41 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
     char* A0 = A16 + p.guardA * RS;  // window row 0
     char* Y0 = Y16 + p.guardY * RS;
 
+    // this lane's fragment position (n, ch) of tile (tm, tn) as a byte offset into an A / Y tile
+    const int frag0 = (wn * TN * 16 + lr) * RS + ((wm * TM) * 16 + lg * 4) * 2;
+    constexpr int FRAG_TN = 16 * RS, FRAG_TM = 32;
+
     f32x4 X[XREG ? TM : 1][XREG ? TN : 1];
     if constexpr (XREG) {
+        if (p.io16) {
+            load_window16<C, W, NTHREADS>((const _Float16*)xb, t0, len, A0, Y0, RS);
+            MV_LAP(tr, TR_LOADX);
+            __syncthreads();
+            MV_LAP(tr, TR_BARRIER);
+            // each wave reads (and, in conv1's epilogue, overwrites) only its own fragment positions of Y
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int n = (wn * TN + tn) * 16 + lr;
-            const int g = t0 + n;
-            const bool in_seq = g >= 0 && g < len;
+            for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) {
-                const int ch = (wm * TM + tm) * 16 + lg * 4;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (in_seq) v = ld4(xb, (long long)g * C + ch, p.io16);
-                X[tm][tn] = v;
-                *(unsigned long long*)(A0 + n * RS + ch * 2) = pack4_bf16_lrelu(v, 0.1f, in_seq);
+                for (int tm = 0; tm < TM; ++tm)
+                    X[tm][tn] = unpack4_f16(*(const unsigned long long*)(Y0 + frag0 + tn * FRAG_TN + tm * FRAG_TM));
+        } else {
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int n = (wn * TN + tn) * 16 + lr;
+                const int g = t0 + n;
+                const bool in_seq = g >= 0 && g < len;
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    const int ch = (wm * TM + tm) * 16 + lg * 4;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (in_seq) v = ld4(xb, (long long)g * C + ch, 0);
+                    X[tm][tn] = v;
+                    *(unsigned long long*)(A0 + n * RS + ch * 2) = pack4_bf16_lrelu(v, 0.1f, in_seq);
+                }
             }
+            MV_LAP(tr, TR_LOADX);
+            __syncthreads();
+            MV_LAP(tr, TR_BARRIER);
         }
     } else {
         ConvPass cp;
@@ -183,54 +302,72 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
         cp.slope = 0.1f;
         cp.src_f16 = p.io16;
         stage_tile<true, NTHREADS>(A0, cp, xb, t0, W, len, RS);
+        MV_LAP(tr, TR_LOADX);
+        __syncthreads();
+        MV_LAP(tr, TR_BARRIER);
     }
 
     f32x4 acc[TM][TN];
     const long long mtile_stride = (long long)p.K * NKC * 64;
     const long long woff = (long long)(wm * TM) * mtile_stride + lane;
     const int pad2 = (p.K - 1) / 2;
+    const int chq = (wm * TM) * 16 + lg * 4;  // first channel of this lane's tm = 0 fragment
+    const bool out16 = XREG && p.io16;        // final rows leave through the A tile as float16
 
     for (int m = 0; m < p.npair; ++m) {
         const int d = p.dil[m];
         const int pad1 = d * (p.K - 1) / 2;
-        MV_LAP(tr, m == 0 ? TR_LOADX : TR_EPI);
-        __syncthreads();  // A16 complete
-        MV_LAP(tr, TR_BARRIER);
+        if (m > 0) {
+            MV_LAP(tr, TR_EPI);
+            __syncthreads();  // A16 complete
+            MV_LAP(tr, TR_BARRIER);
+        }
+        f32x4 bias[TM];  // loaded ahead of the K loop: its latency hides under the MFMAs
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) bias[tm] = *(const f32x4*)(p.b1[m] + chq + tm * 16);
         conv_window<TM, TN>(acc, A0 + ((wn * TN * 16 + lr) - pad1) * RS + lg * 16, RS, p.K, d, NKC,
                             (const u32x4*)p.w1[m] + woff, mtile_stride);
         MV_LAP(tr, TR_KLOOP);
+        if (interior) {
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            const int ch = (wm * TM + tm) * 16 + lg * 4;
-            const f32x4 bias = *(const f32x4*)(p.b1[m] + ch);
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    *(unsigned long long*)(Y0 + frag0 + tn * FRAG_TN + tm * FRAG_TM) =
+                        pack4_bf16(lrelu4(acc[tm][tn] + bias[tm], 0.1f));
+        } else {
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
-                const int n = (wn * TN + tn) * 16 + lr;
-                const int g = t0 + n;
-                *(unsigned long long*)(Y0 + n * RS + ch * 2) =
-                    pack4_bf16_lrelu(acc[tm][tn] + bias, 0.1f, g >= 0 && g < len);
+                const int g = t0 + (wn * TN + tn) * 16 + lr;
+                const bool keep = g >= 0 && g < len;
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+                    *(unsigned long long*)(Y0 + frag0 + tn * FRAG_TN + tm * FRAG_TM) =
+                        pack4_bf16_lrelu(acc[tm][tn] + bias[tm], 0.1f, keep);
             }
         }
         MV_LAP(tr, TR_EPI);
         __syncthreads();  // Y16 complete, A16 free
         MV_LAP(tr, TR_BARRIER);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) bias[tm] = *(const f32x4*)(p.b2[m] + chq + tm * 16);
         conv_window<TM, TN>(acc, Y0 + ((wn * TN * 16 + lr) - pad2) * RS + lg * 16, RS, p.K, 1, NKC,
                             (const u32x4*)p.w2[m] + woff, mtile_stride);
         MV_LAP(tr, TR_KLOOP);
         if constexpr (XREG) {
             const bool more = m + 1 < p.npair;
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) {
-                const int ch = (wm * TM + tm) * 16 + lg * 4;
-                const f32x4 bias = *(const f32x4*)(p.b2[m] + ch);
+            for (int tn = 0; tn < TN; ++tn) {
+                const int g = t0 + (wn * TN + tn) * 16 + lr;
+                const bool keep = interior || (g >= 0 && g < len);
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn) {
-                    const int n = (wn * TN + tn) * 16 + lr;
-                    const int g = t0 + n;
-                    X[tm][tn] = (acc[tm][tn] + bias) + X[tm][tn];
+                for (int tm = 0; tm < TM; ++tm) {
+                    X[tm][tn] = (acc[tm][tn] + bias[tm]) + X[tm][tn];
+                    unsigned long long* dst = (unsigned long long*)(A0 + frag0 + tn * FRAG_TN + tm * FRAG_TM);
                     if (more)
-                        *(unsigned long long*)(A0 + n * RS + ch * 2) =
-                            pack4_bf16_lrelu(X[tm][tn], 0.1f, g >= 0 && g < len);
+                        *dst = pack4_bf16_lrelu(X[tm][tn], 0.1f, keep);
+                    else if (out16)
+                        *dst = pack4_f16_sat(X[tm][tn]);
                 }
             }
         }
@@ -238,8 +375,14 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
 
     MV_LAP(tr, TR_EPI);
     // ---- store the rows the halo has not reached, with the MRF accumulation of models.py:154-160
-    void* ob = p.io16 ? (void*)((_Float16*)p.out + (long long)b * p.batch_stride)
-                      : (void*)((float*)p.out + (long long)b * p.batch_stride);
+    if (out16) {
+        __syncthreads();  // the float16 result tile (in A16) is complete
+        MV_LAP(tr, TR_BARRIER);
+        store_window16<C, NTHREADS>((_Float16*)ob, A0, RS, t0, p.H, p.NT, len, p.mode, p.div);
+        MV_LAP(tr, TR_STORE);
+        MV_FLUSH(tr, (C << 16) | (p.K << 8) | p.npair);
+        return;
+    }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         const int ch = (wm * TM + tm) * 16 + lg * 4;
@@ -313,6 +456,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
     constexpr int NTHREADS = WM * WN * 64;
     constexpr int RS = C * 2 + kLdsRowPad;
     constexpr int NKC = C / 32;
+    constexpr int PS = 9;  // floats per row of the conv_post partial table (7 taps, odd stride)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int b = blockIdx.y;
@@ -334,6 +478,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
         return;
     }
     const int t0 = out0 - p.H;
+    const bool interior = t0 >= 0 && t0 + W <= len;
     MV_TRACER(tr);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -359,6 +504,9 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
     }
     char* A0 = A16 + p.guardA * RS;
     char* Y0 = Y16 + p.guardY * RS;
+    const int frag0 = (wn * TN * 16 + lr) * RS + ((wm * TM) * 16 + lg * 4) * 2;
+    constexpr int FRAG_TN = 16 * RS, FRAG_TM = 32;
+    const int chq = (wm * TM) * 16 + lg * 4;
 
     f32x4 X[TM][TN], SUM[TM][TN], acc[TM][TN];
     for (int j = 0; j < p.nrb; ++j) {
@@ -369,59 +517,85 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
         MV_LAP(tr, j == 0 ? TR_SETUP : TR_EPI);
         if (j > 0) __syncthreads();  // every wave is done reading A16 / Y16 of the previous ResBlock
         MV_LAP(tr, TR_BARRIER);
+        if (p.io16) {
+            load_window16<C, W, NTHREADS>((const _Float16*)xb, t0, len, A0, Y0, RS);
+            MV_LAP(tr, TR_LOADX);
+            __syncthreads();
+            MV_LAP(tr, TR_BARRIER);
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int n = (wn * TN + tn) * 16 + lr;
-            const int g = t0 + n;
-            const bool in_seq = g >= 0 && g < len;
+            for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) {
-                const int ch = (wm * TM + tm) * 16 + lg * 4;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (in_seq) v = ld4(xb, (long long)g * C + ch, p.io16);
-                X[tm][tn] = v;
-                *(unsigned long long*)(A0 + n * RS + ch * 2) = pack4_bf16_lrelu(v, 0.1f, in_seq);
+                for (int tm = 0; tm < TM; ++tm)
+                    X[tm][tn] = unpack4_f16(*(const unsigned long long*)(Y0 + frag0 + tn * FRAG_TN + tm * FRAG_TM));
+        } else {
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int n = (wn * TN + tn) * 16 + lr;
+                const int g = t0 + n;
+                const bool in_seq = g >= 0 && g < len;
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    const int ch = (wm * TM + tm) * 16 + lg * 4;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (in_seq) v = ld4(xb, (long long)g * C + ch, 0);
+                    X[tm][tn] = v;
+                    *(unsigned long long*)(A0 + n * RS + ch * 2) = pack4_bf16_lrelu(v, 0.1f, in_seq);
+                }
             }
+            MV_LAP(tr, TR_LOADX);
+            __syncthreads();
+            MV_LAP(tr, TR_BARRIER);
         }
         for (int m = 0; m < 3; ++m) {
             const int d = p.dil[j][m];
             const int pad1 = d * (K - 1) / 2;
-            MV_LAP(tr, m == 0 ? TR_LOADX : TR_EPI);
-            __syncthreads();
-            MV_LAP(tr, TR_BARRIER);
+            if (m > 0) {
+                MV_LAP(tr, TR_EPI);
+                __syncthreads();
+                MV_LAP(tr, TR_BARRIER);
+            }
+            f32x4 bias[TM];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) bias[tm] = *(const f32x4*)(p.b1[j][m] + chq + tm * 16);
             conv_window<TM, TN>(acc, A0 + ((wn * TN * 16 + lr) - pad1) * RS + lg * 16, RS, K, d, NKC,
                                 (const u32x4*)p.w1[j][m] + woff, mtile_stride);
             MV_LAP(tr, TR_KLOOP);
+            if (interior) {
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) {
-                const int ch = (wm * TM + tm) * 16 + lg * 4;
-                const f32x4 bias = *(const f32x4*)(p.b1[j][m] + ch);
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        *(unsigned long long*)(Y0 + frag0 + tn * FRAG_TN + tm * FRAG_TM) =
+                            pack4_bf16(lrelu4(acc[tm][tn] + bias[tm], 0.1f));
+            } else {
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) {
-                    const int n = (wn * TN + tn) * 16 + lr;
-                    const int g = t0 + n;
-                    *(unsigned long long*)(Y0 + n * RS + ch * 2) =
-                        pack4_bf16_lrelu(acc[tm][tn] + bias, 0.1f, g >= 0 && g < len);
+                    const int g = t0 + (wn * TN + tn) * 16 + lr;
+                    const bool keep = g >= 0 && g < len;
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+                        *(unsigned long long*)(Y0 + frag0 + tn * FRAG_TN + tm * FRAG_TM) =
+                            pack4_bf16_lrelu(acc[tm][tn] + bias[tm], 0.1f, keep);
                 }
             }
             MV_LAP(tr, TR_EPI);
             __syncthreads();
             MV_LAP(tr, TR_BARRIER);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) bias[tm] = *(const f32x4*)(p.b2[j][m] + chq + tm * 16);
             conv_window<TM, TN>(acc, Y0 + ((wn * TN * 16 + lr) - pad2) * RS + lg * 16, RS, K, 1, NKC,
                                 (const u32x4*)p.w2[j][m] + woff, mtile_stride);
             MV_LAP(tr, TR_KLOOP);
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) {
-                const int ch = (wm * TM + tm) * 16 + lg * 4;
-                const f32x4 bias = *(const f32x4*)(p.b2[j][m] + ch);
+            for (int tn = 0; tn < TN; ++tn) {
+                const int g = t0 + (wn * TN + tn) * 16 + lr;
+                const bool keep = interior || (g >= 0 && g < len);
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn) {
-                    const int n = (wn * TN + tn) * 16 + lr;
-                    const int g = t0 + n;
-                    X[tm][tn] = (acc[tm][tn] + bias) + X[tm][tn];
+                for (int tm = 0; tm < TM; ++tm) {
+                    X[tm][tn] = (acc[tm][tn] + bias[tm]) + X[tm][tn];
                     if (m < 2)
-                        *(unsigned long long*)(A0 + n * RS + ch * 2) =
-                            pack4_bf16_lrelu(X[tm][tn], 0.1f, g >= 0 && g < len);
+                        *(unsigned long long*)(A0 + frag0 + tn * FRAG_TN + tm * FRAG_TM) =
+                            pack4_bf16_lrelu(X[tm][tn], 0.1f, keep);
                 }
             }
         }
@@ -439,17 +613,28 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
 
     MV_LAP(tr, TR_EPI);
     if (!p.post_w) {
-        void* ob = p.io16 ? (void*)((_Float16*)p.out + (long long)b * p.batch_stride)
-                          : (void*)((float*)p.out + (long long)b * p.batch_stride);
+        if (p.io16) {
+            // A16 is free since the barrier before the last conv2: the mean leaves through it as float16
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            const int ch = (wm * TM + tm) * 16 + lg * 4;
+            for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                const int n = (wn * TN + tn) * 16 + lr;
-                const int g = t0 + n;
-                if (n < p.H || n >= p.H + p.NT || g >= len) continue;
-                st4(ob, (long long)g * C + ch, SUM[tm][tn], p.io16);
+                for (int tm = 0; tm < TM; ++tm)
+                    *(unsigned long long*)(A0 + frag0 + tn * FRAG_TN + tm * FRAG_TM) = pack4_f16_sat(SUM[tm][tn]);
+            __syncthreads();
+            store_window16<C, NTHREADS>((_Float16*)p.out + (long long)b * p.batch_stride, A0, RS, t0, p.H, p.NT, len,
+                                        ACC_STORE, 1.f);
+        } else {
+            float* ob = (float*)p.out + (long long)b * p.batch_stride;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int ch = (wm * TM + tm) * 16 + lg * 4;
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const int n = (wn * TN + tn) * 16 + lr;
+                    const int g = t0 + n;
+                    if (n < p.H || n >= p.H + p.NT || g >= len) continue;
+                    st4(ob, (long long)g * C + ch, SUM[tm][tn], 0);
+                }
             }
         }
         MV_LAP(tr, TR_STORE);
@@ -457,23 +642,48 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
         return;
     }
 
-    // ---- fused conv_post: M[n][c] = lrelu(mean, 0.01) (zero outside the sequence) as fp32 in LDS,
-    //      then one output sample per thread: tanh(b + sum_k sum_c w[k][c] * M[n+k-3][c])
-    __syncthreads();  // all waves are done with A16 / Y16
-    float* M = (float*)smem;  // [W][C] fp32 = W*C*4 bytes <= the two bf16 tiles
+    // ---- fused conv_post (models.py:161-163): y[t] = tanh(b + sum_k sum_c w[k][c] * lrelu(mean, 0.01)[t+k-3][c]).
+    // Pass 1, from registers: every lane dots its 4*TM channels of each of its rows with the 7 taps, the four
+    // lanes (lg) that share a row add up through ds_bpermute, and P[wm][n][k] lands in LDS (in the A tile,
+    // which no wave reads any more).  Pass 2: one output sample per thread sums 7*WM entries of P.
+    float* P = (float*)smem;  // [WM][W][PS]
+    {
+        f32x4 wk[7][TM];
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-        const int ch = (wm * TM + tm) * 16 + lg * 4;
+        for (int k = 0; k < 7; ++k)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) wk[k][tm] = *(const f32x4*)(p.post_w + k * C + chq + tm * 16);
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             const int n = (wn * TN + tn) * 16 + lr;
             const int g = t0 + n;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (g >= 0 && g < len) {
+            const bool keep = g >= 0 && g < len;
+            float part[7];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = lrelu(SUM[tm][tn][i], 0.01f);
+            for (int k = 0; k < 7; ++k) part[k] = 0.f;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                f32x4 v = lrelu4(SUM[tm][tn], 0.01f);
+                if (!keep) v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 7; ++k) {
+                    part[k] += v[0] * wk[k][tm][0];
+                    part[k] += v[1] * wk[k][tm][1];
+                    part[k] += v[2] * wk[k][tm][2];
+                    part[k] += v[3] * wk[k][tm][3];
+                }
             }
-            *(f32x4*)(M + n * C + ch) = v;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                part[k] += __shfl_xor(part[k], 16);
+                part[k] += __shfl_xor(part[k], 32);
+            }
+            // lane lg writes taps lg and lg + 4
+            float* row = P + ((size_t)wm * W + n) * PS;
+            const float lo = lg == 0 ? part[0] : lg == 1 ? part[1] : lg == 2 ? part[2] : part[3];
+            const float hi = lg == 0 ? part[4] : lg == 1 ? part[5] : part[6];
+            row[lg] = lo;
+            if (lg < 3) row[lg + 4] = hi;
         }
     }
     __syncthreads();
@@ -486,18 +696,9 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
         if (t < len) {
             float a = bias;
 #pragma unroll
-            for (int k = 0; k < 7; ++k) {
-                const f32x4* mr = (const f32x4*)(M + (n + k - 3) * C);
-                const f32x4* wr = (const f32x4*)(p.post_w + k * C);
+            for (int k = 0; k < 7; ++k)
 #pragma unroll
-                for (int c = 0; c < C / 4; ++c) {
-                    const f32x4 v = mr[c], q = wr[c];
-                    a += v[0] * q[0];
-                    a += v[1] * q[1];
-                    a += v[2] * q[2];
-                    a += v[3] * q[3];
-                }
-            }
+                for (int w = 0; w < WM; ++w) a += P[((size_t)w * W + (n + k - 3)) * PS + k];
             y = tanhf(a);
         }
         if (p.wav_pcm16)
