@@ -82,6 +82,7 @@ struct FusedRbParams {
     int io16;
     long long batch_stride;
     const int32_t* lengths;
+    int B;
     int Tmax;
     int rows_per_frame;
     int K;        // kernel size of every conv in this ResBlock
@@ -136,29 +137,52 @@ __device__ __forceinline__ f32x4 unpack4_f16(unsigned long long q) {
 }
 
 // Coalesced window load (float16 activations): rows [t0, t0+W) x C channels of one sequence, 16 bytes per
-// lane along the channel axis, every load of a thread issued before the first is consumed.  Each unit is
-// written twice: raw float16 into the Y tile (from where every wave afterwards picks the fragments of its
-// fp32 residual registers) and bf16(lrelu(x)) into the A tile (conv1's B operand).  Rows outside [0, len)
-// are zeros in both.
+// lane along the channel axis.  issue_window16 puts every load of the thread in flight (into registers);
+// commit_window16 writes each unit twice: raw float16 into the Y tile (from where every wave afterwards picks
+// the fragments of its fp32 residual registers) and bf16(lrelu(x)) into the A tile (conv1's B operand).
+// Rows outside [0, len) are zeros in both.  The two halves are separate so that a persistent block can have
+// the NEXT window's rows in flight while it still computes the current one.
+// threadIdx.x behind an opaque move: index arithmetic derived from it is recomputed where it is used
+// instead of being hoisted out of the persistent window loop (where it would sit in ~40 VGPRs through
+// every K loop)
+__device__ __forceinline__ int tid_here() {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
 template <int C, int W, int NTHREADS>
-__device__ __forceinline__ void load_window16(const _Float16* xb, int t0, int len, char* A0, char* Y0, int RS) {
-    constexpr int UPR = C / 8;
-    constexpr int TOTAL = W * UPR;
-    constexpr int PER = (TOTAL + NTHREADS - 1) / NTHREADS;
-    u32x4 raw[PER];
+struct WinLoad {
+    static constexpr int UPR = C / 8;
+    static constexpr int TOTAL = W * UPR;
+    static constexpr int PER = (TOTAL + NTHREADS - 1) / NTHREADS;
+};
+
+template <int C, int W, int NTHREADS>
+__device__ __forceinline__ void issue_window16(const _Float16* xb, int t0, int len,
+                                               u32x4 (&raw)[WinLoad<C, W, NTHREADS>::PER]) {
+    const int tid = tid_here();
+    using WL = WinLoad<C, W, NTHREADS>;
 #pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const int idx = threadIdx.x + k * NTHREADS;
-        const int r = idx / UPR, u = idx - r * UPR;
+    for (int k = 0; k < WL::PER; ++k) {
+        const int idx = tid + k * NTHREADS;
+        const int r = idx / WL::UPR, u = idx - r * WL::UPR;
         const int g = t0 + r;
         raw[k] = u32x4{0u, 0u, 0u, 0u};
-        if (idx < TOTAL && g >= 0 && g < len) raw[k] = *(const u32x4*)(xb + (long long)g * C + u * 8);
+        if (idx < WL::TOTAL && g >= 0 && g < len) raw[k] = *(const u32x4*)(xb + (long long)g * C + u * 8);
     }
+}
+
+template <int C, int W, int NTHREADS>
+__device__ __forceinline__ void commit_window16(const u32x4 (&raw)[WinLoad<C, W, NTHREADS>::PER], char* A0, char* Y0,
+                                                int RS) {
+    const int tid = tid_here();
+    using WL = WinLoad<C, W, NTHREADS>;
 #pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const int idx = threadIdx.x + k * NTHREADS;
-        if (idx >= TOTAL) continue;
-        const int r = idx / UPR, u = idx - r * UPR;
+    for (int k = 0; k < WL::PER; ++k) {
+        const int idx = tid + k * NTHREADS;
+        if (idx >= WL::TOTAL) continue;
+        const int r = idx / WL::UPR, u = idx - r * WL::UPR;
         const f16x8 h = __builtin_bit_cast(f16x8, raw[k]);
         const f32x4 lo = lrelu4(f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]}, 0.1f);
         const f32x4 hi = lrelu4(f32x4{(float)h[4], (float)h[5], (float)h[6], (float)h[7]}, 0.1f);
@@ -169,17 +193,80 @@ __device__ __forceinline__ void load_window16(const _Float16* xb, int t0, int le
     }
 }
 
+// the window in flight -> tile T0 as raw float16 (fused_rb_kernel converts it in place, fragment by fragment)
+template <int C, int W, int NTHREADS>
+__device__ __forceinline__ void commit_raw16(const u32x4 (&raw)[WinLoad<C, W, NTHREADS>::PER], char* T0, int RS) {
+    const int tid = tid_here();
+    using WL = WinLoad<C, W, NTHREADS>;
+#pragma unroll
+    for (int k = 0; k < WL::PER; ++k) {
+        const int idx = tid + k * NTHREADS;
+        if (idx >= WL::TOTAL) continue;
+        const int r = idx / WL::UPR, u = idx - r * WL::UPR;
+        *(u32x4*)(T0 + r * RS + u * 16) = raw[k];
+    }
+}
+
+template <int C, int W, int NTHREADS>
+__device__ __forceinline__ void load_window16(const _Float16* xb, int t0, int len, char* A0, char* Y0, int RS) {
+    u32x4 raw[WinLoad<C, W, NTHREADS>::PER];
+    issue_window16<C, W, NTHREADS>(xb, t0, len, raw);
+    commit_window16<C, W, NTHREADS>(raw, A0, Y0, RS);
+}
+
+// Persistent blocks walk the list of (sequence, window) pairs that actually exist: cum[b] = number of
+// windows of the sequences before b (window = NT output rows), built once per block by wave 0.
+constexpr int kMaxSeq = 1024;
+
+__device__ __forceinline__ int window_table(int* cum, const int32_t* lengths, int B, int Tmax, int rpf, int NT) {
+    if (threadIdx.x < 64) {
+        int carry = 0;
+        for (int base = 0; base < B; base += 64) {
+            const int i = base + (int)threadIdx.x;
+            int v = 0;
+            if (i < B) {
+                const int len = (lengths ? lengths[i] : Tmax) * rpf;
+                v = (len + NT - 1) / NT;
+            }
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(v, o);
+                if ((int)threadIdx.x >= o) v += t;
+            }
+            if (i < B) cum[i + 1] = carry + v;
+            carry += __shfl(v, 63);
+        }
+        if (threadIdx.x == 0) cum[0] = 0;
+    }
+    __syncthreads();
+    return cum[B];
+}
+
+// largest b with cum[b] <= v  (v < cum[B])
+__device__ __forceinline__ int find_seq(const int* cum, int B, int v) {
+    int lo = 0, hi = B;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (cum[mid] <= v)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
 // Coalesced window store (float16 activations): rows [H, H+NT) of the float16 tile at T0 (row stride RS)
 // go to rows t0+H.. of the output, 16 bytes per lane, with the MRF accumulation of models.py:154-160.
 template <int C, int NTHREADS>
 __device__ __forceinline__ void store_window16(_Float16* ob, const char* T0, int RS, int t0, int H, int NT, int len,
                                                int mode, float div) {
+    const int tid = tid_here();
     constexpr int UPR = C / 8;
     constexpr int U = 4;
     int rows = len - (t0 + H);
     rows = rows < NT ? rows : NT;
     const int total = rows * UPR;
-    for (int base = threadIdx.x; base < total; base += NTHREADS * U) {
+    for (int base = tid; base < total; base += NTHREADS * U) {
         u32x4 old[U];
         if (mode != ACC_STORE) {
 #pragma unroll
@@ -218,16 +305,16 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
     constexpr int NTHREADS = WM * WN * 64;
     constexpr int RS = C * 2 + kLdsRowPad;
     constexpr int NKC = C / 32;
+    using WL = WinLoad<C, W, NTHREADS>;
     static_assert(TM * 16 * WM == C, "C must split evenly over the M waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int cum_s[kMaxSeq + 1];
 
-    const int b = blockIdx.y;
-    const int len = (p.lengths ? p.lengths[b] : p.Tmax) * p.rows_per_frame;
-    const int out0 = blockIdx.x * p.NT;  // first row this block writes
-    if (out0 >= len) return;
+    // ---- persistent block: windows v = blockIdx.x, + gridDim.x, ... of the V that exist
+    const int V = window_table(cum_s, p.lengths, p.B, p.Tmax, p.rows_per_frame, p.NT);
+    int v = blockIdx.x;
+    if (v >= V) return;
     MV_TRACER(tr);
-    const int t0 = out0 - p.H;           // global row of window row 0
-    const bool interior = t0 >= 0 && t0 + W <= len;  // no row of the window needs masking
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave - wm * WN;
@@ -235,10 +322,6 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
 
     char* A16 = smem;                                   // rows [-guardA, W + guardA)
     char* Y16 = smem + (W + 2 * p.guardA) * RS;         // rows [-guardY, W + guardY)
-    const void* xb = p.io16 ? (const void*)((const _Float16*)p.x + (long long)b * p.batch_stride)
-                            : (const void*)((const float*)p.x + (long long)b * p.batch_stride);
-    void* ob = p.io16 ? (void*)((_Float16*)p.out + (long long)b * p.batch_stride)
-                      : (void*)((float*)p.out + (long long)b * p.batch_stride);
 
     // zero the guard rows once (they stand for rows outside the window; their values only reach
     // outputs inside the halo, but they must be finite)
@@ -262,156 +345,214 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
     const int frag0 = (wn * TN * 16 + lr) * RS + ((wm * TM) * 16 + lg * 4) * 2;
     constexpr int FRAG_TN = 16 * RS, FRAG_TM = 32;
 
-    f32x4 X[XREG ? TM : 1][XREG ? TN : 1];
-    if constexpr (XREG) {
-        if (p.io16) {
-            load_window16<C, W, NTHREADS>((const _Float16*)xb, t0, len, A0, Y0, RS);
-            MV_LAP(tr, TR_LOADX);
-            __syncthreads();
-            MV_LAP(tr, TR_BARRIER);
-            // each wave reads (and, in conv1's epilogue, overwrites) only its own fragment positions of Y
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
-                    X[tm][tn] = unpack4_f16(*(const unsigned long long*)(Y0 + frag0 + tn * FRAG_TN + tm * FRAG_TM));
-        } else {
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                const int n = (wn * TN + tn) * 16 + lr;
-                const int g = t0 + n;
-                const bool in_seq = g >= 0 && g < len;
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm) {
-                    const int ch = (wm * TM + tm) * 16 + lg * 4;
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (in_seq) v = ld4(xb, (long long)g * C + ch, 0);
-                    X[tm][tn] = v;
-                    *(unsigned long long*)(A0 + n * RS + ch * 2) = pack4_bf16_lrelu(v, 0.1f, in_seq);
-                }
-            }
-            MV_LAP(tr, TR_LOADX);
-            __syncthreads();
-            MV_LAP(tr, TR_BARRIER);
-        }
-    } else {
-        ConvPass cp;
-        cp.row_stride = C;
-        cp.cin_off = 0;
-        cp.cb = C;
-        cp.slope = 0.1f;
-        cp.src_f16 = p.io16;
-        stage_tile<true, NTHREADS>(A0, cp, xb, t0, W, len, RS);
-        MV_LAP(tr, TR_LOADX);
-        __syncthreads();
-        MV_LAP(tr, TR_BARRIER);
-    }
-
-    f32x4 acc[TM][TN];
     const long long mtile_stride = (long long)p.K * NKC * 64;
     const long long woff = (long long)(wm * TM) * mtile_stride + lane;
     const int pad2 = (p.K - 1) / 2;
     const int chq = (wm * TM) * 16 + lg * 4;  // first channel of this lane's tm = 0 fragment
-    const bool out16 = XREG && p.io16;        // final rows leave through the A tile as float16
+    const bool io16x = XREG && p.io16;        // float16 windows come and go through LDS, next one prefetched
 
-    for (int m = 0; m < p.npair; ++m) {
-        const int d = p.dil[m];
-        const int pad1 = d * (p.K - 1) / 2;
-        if (m > 0) {
-            MV_LAP(tr, TR_EPI);
-            __syncthreads();  // A16 complete
-            MV_LAP(tr, TR_BARRIER);
+    int b = find_seq(cum_s, p.B, v);
+    int len = (p.lengths ? p.lengths[b] : p.Tmax) * p.rows_per_frame;
+    int t0 = (v - cum_s[b]) * p.NT - p.H;     // global row of window row 0
+    if constexpr (XREG) {
+        if (io16x) {  // the block's first window arrives synchronously, every later one is prefetched
+            u32x4 raw[WL::PER];
+            issue_window16<C, W, NTHREADS>((const _Float16*)p.x + (long long)b * p.batch_stride, t0, len, raw);
+            commit_raw16<C, W, NTHREADS>(raw, A0, RS);
+            __syncthreads();
         }
-        f32x4 bias[TM];  // loaded ahead of the K loop: its latency hides under the MFMAs
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) bias[tm] = *(const f32x4*)(p.b1[m] + chq + tm * 16);
-        conv_window<TM, TN>(acc, A0 + ((wn * TN * 16 + lr) - pad1) * RS + lg * 16, RS, p.K, d, NKC,
-                            (const u32x4*)p.w1[m] + woff, mtile_stride);
-        MV_LAP(tr, TR_KLOOP);
-        if (interior) {
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
+    }
+    MV_LAP(tr, TR_SETUP);
+
+    f32x4 X[XREG ? TM : 1][XREG ? TN : 1];
+    f32x4 acc[TM][TN];
+    for (;;) {
+        const bool interior = t0 >= 0 && t0 + W <= len;  // no row of the window needs masking
+        const void* xb = p.io16 ? (const void*)((const _Float16*)p.x + (long long)b * p.batch_stride)
+                                : (const void*)((const float*)p.x + (long long)b * p.batch_stride);
+        void* ob = p.io16 ? (void*)((_Float16*)p.out + (long long)b * p.batch_stride)
+                          : (void*)((float*)p.out + (long long)b * p.batch_stride);
+        if constexpr (XREG) {
+            if (io16x) {
+                // The A tile holds the window as raw float16 (rows outside the sequence are zeros).  Each lane
+                // takes its own fragments as the fp32 residual and leaves bf16(lrelu(x)) in their place.
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
-                    *(unsigned long long*)(Y0 + frag0 + tn * FRAG_TN + tm * FRAG_TM) =
-                        pack4_bf16(lrelu4(acc[tm][tn] + bias[tm], 0.1f));
-        } else {
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                const int g = t0 + (wn * TN + tn) * 16 + lr;
-                const bool keep = g >= 0 && g < len;
+                    for (int tm = 0; tm < TM; ++tm) {
+                        unsigned long long* q = (unsigned long long*)(A0 + frag0 + tn * FRAG_TN + tm * FRAG_TM);
+                        X[tm][tn] = unpack4_f16(*q);
+                        *q = pack4_bf16(lrelu4(X[tm][tn], 0.1f));
+                    }
+            } else {
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const int n = (wn * TN + tn) * 16 + lr;
+                    const int g = t0 + n;
+                    const bool in_seq = g >= 0 && g < len;
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) {
+                        const int ch = (wm * TM + tm) * 16 + lg * 4;
+                        f32x4 q = {0.f, 0.f, 0.f, 0.f};
+                        if (in_seq) q = ld4(xb, (long long)g * C + ch, p.io16);
+                        X[tm][tn] = q;
+                        *(unsigned long long*)(A0 + n * RS + ch * 2) = pack4_bf16_lrelu(q, 0.1f, in_seq);
+                    }
+                }
+            }
+        } else {
+            ConvPass cp;
+            cp.row_stride = C;
+            cp.cin_off = 0;
+            cp.cb = C;
+            cp.slope = 0.1f;
+            cp.src_f16 = p.io16;
+            stage_tile<true, NTHREADS>(A0, cp, xb, t0, W, len, RS);
+        }
+        MV_LAP(tr, TR_LOADX);
+        __syncthreads();  // A16 complete
+        MV_LAP(tr, TR_BARRIER);
+
+        // the window after this one (its rows are requested while this one is still being computed)
+        const int vn = v + (int)gridDim.x;
+        const bool has_next = vn < V;
+        int bn = 0, lenn = 0, t0n = 0;
+        if (has_next) {
+            bn = find_seq(cum_s, p.B, vn);
+            lenn = (p.lengths ? p.lengths[bn] : p.Tmax) * p.rows_per_frame;
+            t0n = (vn - cum_s[bn]) * p.NT - p.H;
+        }
+
+        for (int m = 0; m < p.npair; ++m) {
+            const int d = p.dil[m];
+            const int pad1 = d * (p.K - 1) / 2;
+            if (m > 0) {
+                MV_LAP(tr, TR_EPI);
+                __syncthreads();  // A16 complete
+                MV_LAP(tr, TR_BARRIER);
+            }
+            f32x4 bias[TM];  // loaded ahead of the K loop: its latency hides under the MFMAs
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) bias[tm] = *(const f32x4*)(p.b1[m] + chq + tm * 16);
+            conv_window<TM, TN>(acc, A0 + ((wn * TN * 16 + lr) - pad1) * RS + lg * 16, RS, p.K, d, NKC,
+                                (const u32x4*)p.w1[m] + woff, mtile_stride);
+            MV_LAP(tr, TR_KLOOP);
+            // Prefetch: conv1 of the last pair is done with the A tile after the next barrier and nothing reads
+            // it again until the next window, so the next window's rows are requested here (their HBM latency
+            // hides under this epilogue and the barrier) and dropped into the A tile before conv2 starts.
+            const bool pf = XREG && io16x && has_next && m == p.npair - 1;
+            u32x4 raw[XREG ? WL::PER : 1];
+            if constexpr (XREG) {
+                if (pf)
+                    issue_window16<C, W, NTHREADS>((const _Float16*)p.x + (long long)bn * p.batch_stride, t0n, lenn,
+                                                   raw);
+            }
+            if (interior) {
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
-                    *(unsigned long long*)(Y0 + frag0 + tn * FRAG_TN + tm * FRAG_TM) =
-                        pack4_bf16_lrelu(acc[tm][tn] + bias[tm], 0.1f, keep);
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        *(unsigned long long*)(Y0 + frag0 + tn * FRAG_TN + tm * FRAG_TM) =
+                            pack4_bf16(lrelu4(acc[tm][tn] + bias[tm], 0.1f));
+            } else {
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const int g = t0 + (wn * TN + tn) * 16 + lr;
+                    const bool keep = g >= 0 && g < len;
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+                        *(unsigned long long*)(Y0 + frag0 + tn * FRAG_TN + tm * FRAG_TM) =
+                            pack4_bf16_lrelu(acc[tm][tn] + bias[tm], 0.1f, keep);
+                }
             }
-        }
-        MV_LAP(tr, TR_EPI);
-        __syncthreads();  // Y16 complete, A16 free
-        MV_LAP(tr, TR_BARRIER);
+            MV_LAP(tr, TR_EPI);
+            __syncthreads();  // Y16 complete, A16 free
+            MV_LAP(tr, TR_BARRIER);
+            if constexpr (XREG) {
+                if (pf) commit_raw16<C, W, NTHREADS>(raw, A0, RS);
+            }
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) bias[tm] = *(const f32x4*)(p.b2[m] + chq + tm * 16);
-        conv_window<TM, TN>(acc, Y0 + ((wn * TN * 16 + lr) - pad2) * RS + lg * 16, RS, p.K, 1, NKC,
-                            (const u32x4*)p.w2[m] + woff, mtile_stride);
-        MV_LAP(tr, TR_KLOOP);
-        if constexpr (XREG) {
-            const bool more = m + 1 < p.npair;
+            for (int tm = 0; tm < TM; ++tm) bias[tm] = *(const f32x4*)(p.b2[m] + chq + tm * 16);
+            conv_window<TM, TN>(acc, Y0 + ((wn * TN * 16 + lr) - pad2) * RS + lg * 16, RS, p.K, 1, NKC,
+                                (const u32x4*)p.w2[m] + woff, mtile_stride);
+            MV_LAP(tr, TR_KLOOP);
+            if constexpr (XREG) {
+                const bool more = m + 1 < p.npair;
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                const int g = t0 + (wn * TN + tn) * 16 + lr;
-                const bool keep = interior || (g >= 0 && g < len);
+                for (int tn = 0; tn < TN; ++tn) {
+                    const int g = t0 + (wn * TN + tn) * 16 + lr;
+                    const bool keep = interior || (g >= 0 && g < len);
 #pragma unroll
-                for (int tm = 0; tm < TM; ++tm) {
-                    X[tm][tn] = (acc[tm][tn] + bias[tm]) + X[tm][tn];
-                    unsigned long long* dst = (unsigned long long*)(A0 + frag0 + tn * FRAG_TN + tm * FRAG_TM);
-                    if (more)
-                        *dst = pack4_bf16_lrelu(X[tm][tn], 0.1f, keep);
-                    else if (out16)
-                        *dst = pack4_f16_sat(X[tm][tn]);
+                    for (int tm = 0; tm < TM; ++tm) {
+                        X[tm][tn] = (acc[tm][tn] + bias[tm]) + X[tm][tn];
+                        if (more)
+                            *(unsigned long long*)(A0 + frag0 + tn * FRAG_TN + tm * FRAG_TM) =
+                                pack4_bf16_lrelu(X[tm][tn], 0.1f, keep);
+                    }
                 }
             }
         }
-    }
 
-    MV_LAP(tr, TR_EPI);
-    // ---- store the rows the halo has not reached, with the MRF accumulation of models.py:154-160
-    if (out16) {
-        __syncthreads();  // the float16 result tile (in A16) is complete
-        MV_LAP(tr, TR_BARRIER);
-        store_window16<C, NTHREADS>((_Float16*)ob, A0, RS, t0, p.H, p.NT, len, p.mode, p.div);
-        MV_LAP(tr, TR_STORE);
-        MV_FLUSH(tr, (C << 16) | (p.K << 8) | p.npair);
-        return;
-    }
+        MV_LAP(tr, TR_EPI);
+        // ---- store the rows the halo has not reached, with the MRF accumulation of models.py:154-160
+        if (io16x) {
+            // the result leaves as float16 through the Y tile (the A tile may already hold the next window)
+            __syncthreads();  // every wave is done reading Y16 as conv2's operand
+            MV_LAP(tr, TR_BARRIER);
+            if constexpr (XREG) {
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-        const int ch = (wm * TM + tm) * 16 + lg * 4;
-        f32x4 bias2 = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (!XREG) bias2 = *(const f32x4*)(p.b2[0] + ch);
+                for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int n = (wn * TN + tn) * 16 + lr;
-            const int g = t0 + n;
-            if (n < p.H || n >= p.H + p.NT || g >= len) continue;
-            const long long e = (long long)g * C + ch;
-            f32x4 v;
-            if constexpr (XREG)
-                v = X[tm][tn];
-            else
-                v = (acc[tm][tn] + bias2) + ld4(xb, e, p.io16);
-            if (p.mode == ACC_ADD) {
-                v += ld4(ob, e, p.io16);
-            } else if (p.mode == ACC_ADD_DIV) {
-                v += ld4(ob, e, p.io16);
-                v[0] = v[0] / p.div;
-                v[1] = v[1] / p.div;
-                v[2] = v[2] / p.div;
-                v[3] = v[3] / p.div;
+                    for (int tm = 0; tm < TM; ++tm)
+                        *(unsigned long long*)(Y0 + frag0 + tn * FRAG_TN + tm * FRAG_TM) = pack4_f16_sat(X[tm][tn]);
             }
-            st4(ob, e, v, p.io16);
+            MV_LAP(tr, TR_EPI);
+            __syncthreads();
+            MV_LAP(tr, TR_BARRIER);
+            store_window16<C, NTHREADS>((_Float16*)ob, Y0, RS, t0, p.H, p.NT, len, p.mode, p.div);
+            // no barrier here: the next window's first barrier ("A16 complete") already separates these reads
+            // of the Y tile from the next conv1 epilogue that overwrites it
+        } else {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int ch = (wm * TM + tm) * 16 + lg * 4;
+                f32x4 bias2 = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (!XREG) bias2 = *(const f32x4*)(p.b2[0] + ch);
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const int n = (wn * TN + tn) * 16 + lr;
+                    const int g = t0 + n;
+                    if (n < p.H || n >= p.H + p.NT || g >= len) continue;
+                    const long long e = (long long)g * C + ch;
+                    f32x4 q;
+                    if constexpr (XREG)
+                        q = X[tm][tn];
+                    else
+                        q = (acc[tm][tn] + bias2) + ld4(xb, e, p.io16);
+                    if (p.mode == ACC_ADD) {
+                        q += ld4(ob, e, p.io16);
+                    } else if (p.mode == ACC_ADD_DIV) {
+                        q += ld4(ob, e, p.io16);
+                        q[0] = q[0] / p.div;
+                        q[1] = q[1] / p.div;
+                        q[2] = q[2] / p.div;
+                        q[3] = q[3] / p.div;
+                    }
+                    st4(ob, e, q, p.io16);
+                }
+            }
+        }
+        MV_LAP(tr, TR_STORE);
+        if (!has_next) break;
+        v = vn;
+        b = bn;
+        len = lenn;
+        t0 = t0n;
+        if (!io16x) {
+            __syncthreads();  // every wave is done with this window's tiles before the next one lands in them
+            MV_LAP(tr, TR_BARRIER);
         }
     }
-    MV_LAP(tr, TR_STORE);
     MV_FLUSH(tr, (C << 16) | (p.K << 8) | p.npair);
 }
 

@@ -17,9 +17,9 @@
 #include "fused_rb.h"
 
 #ifdef MV_TRACE
-static constexpr int kFusedMaxLds = 160 * 1024 - 256;  // the tracer's static LDS comes off the top
+static constexpr int kFusedMaxLds = 160 * 1024 - 4608;  // window table + the tracer's static LDS
 #else
-static constexpr int kFusedMaxLds = 160 * 1024;
+static constexpr int kFusedMaxLds = 160 * 1024 - 4352;  // the kernels' static LDS (window table) comes off the top
 #endif
 #include "handle.h"
 
@@ -353,6 +353,18 @@ static int hifigan_build(HifiganHandle* h, WeightMap& W) {
     return MV_OK;
 }
 
+static int cu_count() {
+    static int n[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (n[dev] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n[dev] = v;
+    }
+    return n[dev];
+}
+
 // Runs pairs [m0, m0+npair) of one ResBlock fused; returns MV_EUNSUPPORTED if the window is too small.
 static int launch_fused_rb(const FusedCfg& fc, const RbPair* pairs, int m0, int npair, int K, const int* dils,
                            const void* x, void* out, long long bs, int rpf, int mode, float div,
@@ -364,6 +376,7 @@ static int launch_fused_rb(const FusedCfg& fc, const RbPair* pairs, int m0, int 
     p.io16 = io16;
     p.batch_stride = bs;
     p.lengths = lengths;
+    p.B = B;
     p.Tmax = Tmax;
     p.rows_per_frame = rpf;
     p.K = K;
@@ -392,9 +405,11 @@ static int launch_fused_rb(const FusedCfg& fc, const RbPair* pairs, int m0, int 
     const int RS = fc.C * 2 + kLdsRowPad;
     const size_t lds = (size_t)(2 * fc.W + 2 * gA + 2 * pad2) * RS;
     static const int pair_pct = env_or("MV_PAIR_MIN_PCT", 60);  // below this the halo recompute costs too much
-    if (p.NT < 16 || lds > kFusedMaxLds || p.NT * 100 < fc.W * pair_pct) return MV_EUNSUPPORTED;
+    if (p.NT < 16 || lds > kFusedMaxLds || p.NT * 100 < fc.W * pair_pct || B > kMaxSeq) return MV_EUNSUPPORTED;
     const long long rows = (long long)Tmax * rpf;
-    dim3 grid((unsigned)((rows + p.NT - 1) / p.NT), (unsigned)B);
+    // persistent blocks, one per CU (LDS allows no more), each walking every gridDim.x-th existing window
+    const long long vmax = ((rows + p.NT - 1) / p.NT) * B;
+    dim3 grid((unsigned)std::min<long long>(vmax, cu_count()));
     if (prof) {
         char nm[128];
         snprintf(nm, sizeof nm, "%s k=%d", fc.name, K);
