@@ -31,6 +31,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kMaxPass = 16;
+constexpr int kMfmaPrio = 3;    // s_setprio while a wave issues an MFMA group: the SIMD's other wave does its loads meanwhile
 constexpr int kLdsRowPad = 32;  // bytes; row stride/16 == 2 (mod 4) makes ds_read_b128 conflict-free
 
 enum { EPI_LINEAR = 0, EPI_GATE = 1 };
@@ -79,8 +80,8 @@ struct ConvParams {
 
 template <bool BF16>
 __device__ __forceinline__ void mma16(f32x4& acc, const u32x4& a, const u32x4& b) {
-#if defined(MV_ABLATE) && MV_ABLATE >= 1
-    // timing-only build (tools/ablate.sh): keep the operands live, issue no MFMA
+#if defined(MV_ABLATE) && (MV_ABLATE & 1)
+    // timing-only build (tools/ablate.sh; MV_ABLATE is a bit mask): keep the operands live, issue no MFMA
     asm volatile("" ::"v"(a), "v"(b));
     return;
 #endif
@@ -202,8 +203,13 @@ __device__ __forceinline__ void load_bgroup(u32x4 (&q)[G], const char* bp, int R
 #pragma unroll
     for (int j = 0; j < G; ++j)
         if (g * G + j < TN) {
-#if defined(MV_ABLATE) && MV_ABLATE >= 2
+#if defined(MV_ABLATE) && (MV_ABLATE & 2)
             q[j] = u32x4{(unsigned)(size_t)bp, 0u, 0u, 0u};  // timing-only build: no LDS read
+#elif defined(MV_ABLATE) && (MV_ABLATE & 16)
+            if (j & 1)  // timing-only build: half the LDS reads
+                q[j] = u32x4{(unsigned)(size_t)bp, 0u, 0u, 0u};
+            else
+                q[j] = *(const u32x4*)(bp + (g * G + j) * 16 * RS);
 #else
             q[j] = *(const u32x4*)(bp + (g * G + j) * 16 * RS);
 #endif
@@ -234,6 +240,7 @@ __device__ __forceinline__ void mma_step(f32x4 (&acc)[TM][TN], const u32x4 (&a)[
         // pin the order: hipcc otherwise sinks every ds_read to just before its MFMA (lgkmcnt(0)
         // after each read), which exposes the full LDS latency at one wave per SIMD
         __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(kMfmaPrio);
 #pragma unroll
         for (int j = 0; j < G; ++j) {
             if (g * G + j < TN) {
@@ -241,6 +248,7 @@ __device__ __forceinline__ void mma_step(f32x4 (&acc)[TM][TN], const u32x4 (&a)[
                 for (int tm = 0; tm < TM; ++tm) mma16<BF16>(acc[tm][g * G + j], a[tm], cur0 ? q0[j] : q1[j]);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -262,14 +270,14 @@ __device__ __forceinline__ void mma_pass(f32x4 (&acc)[TM][TN], const char* lds_b
         const int sn = step < S ? step : S - 1;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
-#if defined(MV_ABLATE) && MV_ABLATE >= 3
+#if defined(MV_ABLATE) && (MV_ABLATE & 4)
             a[tm] = u32x4{(unsigned)sn, 0u, 0u, 0u};  // timing-only build: no weight loads
 #else
             a[tm] = wlane[tm * mtile_stride + (long long)sn * 64];
 #endif
         }
     };
-#if defined(MV_ABLATE) && MV_ABLATE >= 4
+#if defined(MV_ABLATE) && (MV_ABLATE & 8)
     return;  // timing-only build: no K loop at all (staging, epilogues and barriers remain)
 #endif
     fetch(a0, 0);
