@@ -76,6 +76,7 @@ struct ConvParams {
     const void* resid;   // optional, indexed (and typed) like out[0]
     long long resid_batch_stride;
     float div;           // ACC_ADD_DIV divisor
+    int epi_lds;         // linear epilogue, one float16 output: leave through LDS with 16-byte coalesced stores
 };
 
 template <bool BF16>
@@ -389,6 +390,73 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_cl_kernel(const ConvParams p
     if (p.resid) {
         const long long ro = (long long)b * p.resid_batch_stride;
         resid_b = p.out[0].f16 ? (const void*)((const _Float16*)p.resid + ro) : (const void*)((const float*)p.resid + ro);
+    }
+    if constexpr (EPI == EPI_LINEAR && BF16) {
+        if (p.epi_lds) {
+            // The accumulator layout gives every lane 4 channels of one row: stored directly, a wave
+            // instruction touches 16 rows with 8 bytes each.  Instead the block's [NT][MT] tile goes to LDS
+            // as float16 and leaves with 16 bytes per lane along m, which is contiguous in memory for a
+            // Conv1d (m = channel) and for the phase-major transposed conv alike (m = phase*Cout + co).
+            constexpr int TRS = MT * 2 + 16;
+            __syncthreads();  // every wave is done reading the operand tiles
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int ml = (wm * TM + tm) * 16 + lg * 4;
+                const f32x4 bias = *(const f32x4*)(p.bias + blockIdx.y * MT + ml);
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const int nl = (wn * TN + tn) * 16 + lr;
+                    const f32x4 v = acc[tm][tn] + bias;
+                    f16x4 h;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) h[i] = (_Float16)fminf(fmaxf(v[i], -65504.f), 65504.f);
+                    *(f16x4*)(smem + nl * TRS + ml * 2) = h;
+                }
+            }
+            __syncthreads();
+            const ConvOut& o = p.out[0];
+            const long long valid = (long long)len * o.valid_per_frame;
+            _Float16* ob = (_Float16*)o.ptr + (long long)b * o.batch_stride;
+            constexpr int UPR = MT / 8, TOTAL = NT * UPR, U = 4;
+            for (int base = threadIdx.x; base < TOTAL; base += NTHREADS * U) {
+                u32x4 r0[U], r1[U];
+                long long ek[U];
+#pragma unroll
+                for (int k = 0; k < U; ++k) {
+                    const int idx = base + k * NTHREADS;
+                    const int nl = idx / UPR, u = idx - nl * UPR;
+                    const int n = n0 + nl;
+                    const long long e = (long long)n * o.row_stride + blockIdx.y * MT + u * 8 + o.off;
+                    ek[k] = (idx < TOTAL && n < n_ext && e >= 0 && e < valid) ? e : -1;
+                    if (ek[k] >= 0) {
+                        if (resid_b) r0[k] = *(const u32x4*)((const _Float16*)resid_b + e);
+                        if (o.mode != ACC_STORE) r1[k] = *(const u32x4*)(ob + e);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < U; ++k) {
+                    if (ek[k] < 0) continue;
+                    const int idx = base + k * NTHREADS;
+                    const int nl = idx / UPR, u = idx - nl * UPR;
+                    u32x4 v = *(const u32x4*)(smem + nl * TRS + u * 16);
+                    if (resid_b || o.mode != ACC_STORE) {
+                        const f16x8 a = __builtin_bit_cast(f16x8, v);
+                        f16x8 y;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            float t = (float)a[i];
+                            if (resid_b) t += (float)__builtin_bit_cast(f16x8, r0[k])[i];
+                            if (o.mode != ACC_STORE) t += (float)__builtin_bit_cast(f16x8, r1[k])[i];
+                            if (o.mode == ACC_ADD_DIV) t = t / p.div;
+                            y[i] = (_Float16)fminf(fmaxf(t, -65504.f), 65504.f);
+                        }
+                        v = __builtin_bit_cast(u32x4, y);
+                    }
+                    *(u32x4*)(ob + ek[k]) = v;
+                }
+            }
+            return;
+        }
     }
     if constexpr (EPI == EPI_LINEAR) {
 #pragma unroll

@@ -111,6 +111,8 @@ int build_layer(Layer* L, const std::vector<SrcSpec>& srcs, int M, const std::ve
             }
         L->macs_per_n += (double)M * s.C * s.ktaps;
     }
+    // room for the coalescing epilogue's float16 [NT][MT] tile (conv_cl_kernel, epi_lds)
+    if (bf16 && epi == EPI_LINEAR) L->lds_bytes = std::max(L->lds_bytes, (size_t)tc.NT() * (tc.MT() * 2 + 16));
     if (L->lds_bytes > 160 * 1024) {
         set_error("build_layer: needs %zu bytes of LDS", L->lds_bytes);
         return MV_EINVAL;
@@ -278,6 +280,10 @@ int launch_layer(const Layer& L, const SrcBind* srcs, int nsrc, const LaunchArgs
     p.resid = a.resid;
     p.resid_batch_stride = a.resid_batch_stride;
     p.div = a.div;
+    static const int epi_lds_on = env_int("MV_EPI_LDS", 1);
+    p.epi_lds = epi_lds_on && L.bf16 && L.epi == EPI_LINEAR && a.out[0].f16 && a.split >= L.M &&
+                a.out[0].row_stride % 8 == 0 && a.out[0].off % 8 == 0 && a.out[0].valid_per_frame % 8 == 0 &&
+                a.out[0].batch_stride % 8 == 0 && a.resid_batch_stride % 8 == 0;
     const long long n_max = (long long)a.Tmax * a.n_rows_per_frame + a.n_extra;
     if (n_max <= 0 || a.B <= 0) return MV_OK;
     dim3 grid((unsigned)((n_max + tc.NT() - 1) / tc.NT()), (unsigned)(L.M / tc.MT()), (unsigned)a.B);
