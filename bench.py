@@ -80,6 +80,23 @@ def cpu_baseline(torch):
                       f"synthetic mel, batch 1, median of {len(times)} calls, {threads} threads of {cores} host CPUs"}
 
 
+def profiled_traffic(kernel_name, args):
+    """HBM-side bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes (profiles/*_traffic.json),
+    valid for the default bf16 HiFi-GAN batch only; None when there is no matching measurement."""
+    if args.model != "hifigan" or args.dtype != "bf16" or args.batch != 32:
+        return None
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_traffic.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        table = json.load(f)
+    for k, v in table.items():
+        if not k.startswith("_") and kernel_name.startswith(k):
+            return v["bytes_per_launch"]
+    return None
+
+
 def main():
     args = parse()
     import torch
@@ -173,7 +190,7 @@ def main():
         all_ms = sum(r["ms"] for r in rows)
         all_flops = sum(2.0 * r["macs_per_frame"] * frames for r in rows)
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": None, "kernel": top["name"],
+                    "frac": round(achieved / peak, 4), "traffic": profiled_traffic(top["name"], args), "kernel": top["name"],
                     "launches_per_step": top["launches"] // nprof,
                     "avg_launch_us": round(top["ms"] * 1e3 / top["launches"], 2),
                     "flop_per_launch": round(flops / top["launches"]),
