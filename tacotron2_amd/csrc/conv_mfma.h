@@ -168,22 +168,28 @@ __device__ __forceinline__ void stage_tile(char* smem, const ConvPass& cp, const
                 }
             }
         }
+        const bool act = slope != 1.f;  // slope 1 = no activation (WaveGlow, conv_pre): skip the max/mul
 #pragma unroll
         for (int k = 0; k < U; ++k) {
             if (dst[k] < 0) continue;
             u32x4 v;
+            f32x4 y0 = x0[k];
+            if (act) {
+                const f32x4 s0 = y0 * slope;  // leaky_relu as max(x, slope*x), 0 < slope < 1
+                y0 = f32x4{fmaxf(y0[0], s0[0]), fmaxf(y0[1], s0[1]), fmaxf(y0[2], s0[2]), fmaxf(y0[3], s0[3])};
+            }
             if constexpr (BF16) {
-                v[0] = pack_bf16(lrelu(x0[k][0], slope), lrelu(x0[k][1], slope));
-                v[1] = pack_bf16(lrelu(x0[k][2], slope), lrelu(x0[k][3], slope));
-                v[2] = pack_bf16(lrelu(x1[k][0], slope), lrelu(x1[k][1], slope));
-                v[3] = pack_bf16(lrelu(x1[k][2], slope), lrelu(x1[k][3], slope));
+                f32x4 y1 = x1[k];
+                if (act) {
+                    const f32x4 s1 = y1 * slope;
+                    y1 = f32x4{fmaxf(y1[0], s1[0]), fmaxf(y1[1], s1[1]), fmaxf(y1[2], s1[2]), fmaxf(y1[3], s1[3])};
+                }
+                v[0] = pack_bf16(y0[0], y0[1]);
+                v[1] = pack_bf16(y0[2], y0[3]);
+                v[2] = pack_bf16(y1[0], y1[1]);
+                v[3] = pack_bf16(y1[2], y1[3]);
             } else {
-                f32x4 y = x0[k];
-                y[0] = lrelu(y[0], slope);
-                y[1] = lrelu(y[1], slope);
-                y[2] = lrelu(y[2], slope);
-                y[3] = lrelu(y[3], slope);
-                v = __builtin_bit_cast(u32x4, y);
+                v = __builtin_bit_cast(u32x4, y0);
             }
             *(u32x4*)(smem + dst[k]) = v;
         }
@@ -391,46 +397,79 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_cl_kernel(const ConvParams p
         const long long ro = (long long)b * p.resid_batch_stride;
         resid_b = p.out[0].f16 ? (const void*)((const _Float16*)p.resid + ro) : (const void*)((const float*)p.resid + ro);
     }
-    if constexpr (EPI == EPI_LINEAR && BF16) {
+    if constexpr (BF16) {
         if (p.epi_lds) {
             // The accumulator layout gives every lane 4 channels of one row: stored directly, a wave
-            // instruction touches 16 rows with 8 bytes each.  Instead the block's [NT][MT] tile goes to LDS
-            // as float16 and leaves with 16 bytes per lane along m, which is contiguous in memory for a
-            // Conv1d (m = channel) and for the phase-major transposed conv alike (m = phase*Cout + co).
-            constexpr int TRS = MT * 2 + 16;
+            // instruction touches 16 rows with 8 bytes each.  Instead the block's [NT][MO] result tile goes
+            // to LDS as float16 and leaves with 16 bytes per lane along m, which is contiguous in memory for
+            // a Conv1d (m = channel) and for the phase-major transposed conv alike (m = phase*Cout + co).
+            // MO = MT, or MT/2 for the gate epilogue (one output channel per (tanh, sigmoid) row pair).
+            constexpr int MO = EPI == EPI_GATE ? MT / 2 : MT;
+            constexpr int TRS = MO * 2 + 16;
             __syncthreads();  // every wave is done reading the operand tiles
+            if constexpr (EPI == EPI_LINEAR) {
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) {
-                const int ml = (wm * TM + tm) * 16 + lg * 4;
-                const f32x4 bias = *(const f32x4*)(p.bias + blockIdx.y * MT + ml);
+                for (int tm = 0; tm < TM; ++tm) {
+                    const int ml = (wm * TM + tm) * 16 + lg * 4;
+                    const f32x4 bias = *(const f32x4*)(p.bias + blockIdx.y * MT + ml);
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn) {
-                    const int nl = (wn * TN + tn) * 16 + lr;
-                    const f32x4 v = acc[tm][tn] + bias;
-                    f16x4 h;
+                    for (int tn = 0; tn < TN; ++tn) {
+                        const int nl = (wn * TN + tn) * 16 + lr;
+                        const f32x4 v = acc[tm][tn] + bias;
+                        f16x4 h;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) h[i] = (_Float16)fminf(fmaxf(v[i], -65504.f), 65504.f);
-                    *(f16x4*)(smem + nl * TRS + ml * 2) = h;
+                        for (int i = 0; i < 4; ++i) h[i] = (_Float16)fminf(fmaxf(v[i], -65504.f), 65504.f);
+                        *(f16x4*)(smem + nl * TRS + ml * 2) = h;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int tp = 0; tp < TM / 2; ++tp) {
+                    const int mt = (mtile0 + 2 * tp) * 16 + lg * 4;
+                    const f32x4 bt = *(const f32x4*)(p.bias + mt);
+                    const f32x4 bs = *(const f32x4*)(p.bias + mt + 16);
+                    const int cl = ((wm * TM) / 2 + tp) * 16 + lg * 4;
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) {
+                        const int nl = (wn * TN + tn) * 16 + lr;
+                        const f32x4 t = acc[2 * tp][tn] + bt;
+                        const f32x4 sg = acc[2 * tp + 1][tn] + bs;
+                        f16x4 h;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) h[j] = (_Float16)(tanhf(t[j]) * (1.0f / (1.0f + expf(-sg[j]))));
+                        *(f16x4*)(smem + nl * TRS + cl * 2) = h;
+                    }
                 }
             }
             __syncthreads();
-            const ConvOut& o = p.out[0];
+            // a block's M range lies on one side of the split (launch_layer checks split % MT == 0)
+            int mbase = blockIdx.y * MO;
+            const int oi = (EPI == EPI_LINEAR && mbase >= p.split) ? 1 : 0;
+            if (oi) mbase -= p.split;
+            const ConvOut& o = p.out[oi];
             const long long valid = (long long)len * o.valid_per_frame;
-            _Float16* ob = (_Float16*)o.ptr + (long long)b * o.batch_stride;
-            constexpr int UPR = MT / 8, TOTAL = NT * UPR, U = 4;
+            const void* rb = oi ? nullptr : resid_b;
+            constexpr int UPR = MO / 8, TOTAL = NT * UPR, U = 4;
             for (int base = threadIdx.x; base < TOTAL; base += NTHREADS * U) {
-                u32x4 r0[U], r1[U];
+                f32x4 r0[U][2], r1[U][2];
                 long long ek[U];
 #pragma unroll
                 for (int k = 0; k < U; ++k) {
                     const int idx = base + k * NTHREADS;
                     const int nl = idx / UPR, u = idx - nl * UPR;
                     const int n = n0 + nl;
-                    const long long e = (long long)n * o.row_stride + blockIdx.y * MT + u * 8 + o.off;
+                    const long long e = (long long)n * o.row_stride + mbase + u * 8 + o.off;
                     ek[k] = (idx < TOTAL && n < n_ext && e >= 0 && e < valid) ? e : -1;
                     if (ek[k] >= 0) {
-                        if (resid_b) r0[k] = *(const u32x4*)((const _Float16*)resid_b + e);
-                        if (o.mode != ACC_STORE) r1[k] = *(const u32x4*)(ob + e);
+                        if (rb) {
+                            r0[k][0] = ld4(rb, e, o.f16);
+                            r0[k][1] = ld4(rb, e + 4, o.f16);
+                        }
+                        if (o.mode != ACC_STORE) {
+                            const long long eb = (long long)b * o.batch_stride + e;
+                            r1[k][0] = ld4(o.ptr, eb, o.f16);
+                            r1[k][1] = ld4(o.ptr, eb + 4, o.f16);
+                        }
                     }
                 }
 #pragma unroll
@@ -438,21 +477,34 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_cl_kernel(const ConvParams p
                     if (ek[k] < 0) continue;
                     const int idx = base + k * NTHREADS;
                     const int nl = idx / UPR, u = idx - nl * UPR;
-                    u32x4 v = *(const u32x4*)(smem + nl * TRS + u * 16);
-                    if (resid_b || o.mode != ACC_STORE) {
-                        const f16x8 a = __builtin_bit_cast(f16x8, v);
-                        f16x8 y;
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            float t = (float)a[i];
-                            if (resid_b) t += (float)__builtin_bit_cast(f16x8, r0[k])[i];
-                            if (o.mode != ACC_STORE) t += (float)__builtin_bit_cast(f16x8, r1[k])[i];
-                            if (o.mode == ACC_ADD_DIV) t = t / p.div;
-                            y[i] = (_Float16)fminf(fmaxf(t, -65504.f), 65504.f);
-                        }
-                        v = __builtin_bit_cast(u32x4, y);
+                    const u32x4 raw = *(const u32x4*)(smem + nl * TRS + u * 16);
+                    const long long eb = (long long)b * o.batch_stride + ek[k];
+                    if (o.f16 && !rb && o.mode == ACC_STORE) {
+                        *(u32x4*)((_Float16*)o.ptr + eb) = raw;
+                        continue;
                     }
-                    *(u32x4*)(ob + ek[k]) = v;
+                    const f16x8 a = __builtin_bit_cast(f16x8, raw);
+                    f32x4 y[2] = {f32x4{(float)a[0], (float)a[1], (float)a[2], (float)a[3]},
+                                  f32x4{(float)a[4], (float)a[5], (float)a[6], (float)a[7]}};
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        if (rb) y[q] += r0[k][q];
+                        if (o.mode != ACC_STORE) y[q] += r1[k][q];
+                        if (o.mode == ACC_ADD_DIV) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) y[q][i] = y[q][i] / p.div;
+                        }
+                    }
+                    if (o.f16) {
+                        f16x8 hh;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+                            hh[i] = (_Float16)fminf(fmaxf(y[i >> 2][i & 3], -65504.f), 65504.f);
+                        *(f16x8*)((_Float16*)o.ptr + eb) = hh;
+                    } else {
+                        *(f32x4*)((float*)o.ptr + eb) = y[0];
+                        *(f32x4*)((float*)o.ptr + eb + 4) = y[1];
+                    }
                 }
             }
             return;

@@ -28,6 +28,7 @@ const TileCfg kTileCfgs[] = {
     {2, 8, 1, 4},  // 5:   32 x 512
     {4, 8, 1, 4},  // 6:   64 x 512
     {4, 8, 2, 2},  // 7:  128 x 256
+    {4, 8, 4, 2},  // 8:  256 x 256, 8 waves (one block per CU)
 };
 const int kNumTileCfgs = sizeof(kTileCfgs) / sizeof(kTileCfgs[0]);
 
@@ -68,7 +69,11 @@ int build_layer(Layer* L, const std::vector<SrcSpec>& srcs, int M, const std::ve
         set_error("build_layer: tile config %d does not fit M=%d", L->cfg, M);
         return MV_EINVAL;
     }
-    const size_t lds_budget = (size_t)env_int(bf16 ? "MV_LDS_BUDGET_KB" : "MV_LDS_BUDGET_KB_FP32", bf16 ? 64 : 128) * 1024;
+    // 4-wave tiles: two blocks per CU; the 8-wave tile has the CU to itself
+    const bool big = tc.WM * tc.WN >= 8;
+    const size_t lds_budget =
+        (size_t)env_int(bf16 ? (big ? "MV_LDS_BUDGET_KB_BIG" : "MV_LDS_BUDGET_KB") : "MV_LDS_BUDGET_KB_FP32",
+                        bf16 && !big ? 64 : 128) * 1024;
     L->npass = 0;
     L->lds_bytes = 0;
     L->steps_total = 0;
@@ -112,7 +117,7 @@ int build_layer(Layer* L, const std::vector<SrcSpec>& srcs, int M, const std::ve
         L->macs_per_n += (double)M * s.C * s.ktaps;
     }
     // room for the coalescing epilogue's float16 [NT][MT] tile (conv_cl_kernel, epi_lds)
-    if (bf16 && epi == EPI_LINEAR) L->lds_bytes = std::max(L->lds_bytes, (size_t)tc.NT() * (tc.MT() * 2 + 16));
+    if (bf16) L->lds_bytes = std::max(L->lds_bytes, (size_t)tc.NT() * (tc.MT() * (epi == EPI_GATE ? 1 : 2) + 16));
     if (L->lds_bytes > 160 * 1024) {
         set_error("build_layer: needs %zu bytes of LDS", L->lds_bytes);
         return MV_EINVAL;
@@ -176,6 +181,7 @@ static ConvKernel kernel_for(int cfg) {
         case 5: return conv_cl_kernel<BF16, 2, 8, 1, 4, EPI>;
         case 6: return conv_cl_kernel<BF16, 4, 8, 1, 4, EPI>;
         case 7: return conv_cl_kernel<BF16, 4, 8, 2, 2, EPI>;
+        case 8: return conv_cl_kernel<BF16, 4, 8, 4, 2, EPI>;
     }
     return nullptr;
 }
@@ -281,9 +287,15 @@ int launch_layer(const Layer& L, const SrcBind* srcs, int nsrc, const LaunchArgs
     p.resid_batch_stride = a.resid_batch_stride;
     p.div = a.div;
     static const int epi_lds_on = env_int("MV_EPI_LDS", 1);
-    p.epi_lds = epi_lds_on && L.bf16 && L.epi == EPI_LINEAR && a.out[0].f16 && a.split >= L.M &&
-                a.out[0].row_stride % 8 == 0 && a.out[0].off % 8 == 0 && a.out[0].valid_per_frame % 8 == 0 &&
-                a.out[0].batch_stride % 8 == 0 && a.resid_batch_stride % 8 == 0;
+    // the coalescing epilogue (conv_cl_kernel) wants 8-element units that never straddle a validity bound, a
+    // block's M range on one side of the split, and a residual typed and laid out like out[0]
+    const int mo = L.epi == EPI_GATE ? tc.MT() / 2 : tc.MT();
+    const bool two = a.split < L.M;
+    auto unit_ok = [&](const ConvOut& o) {
+        return o.row_stride % 8 == 0 && o.off % 8 == 0 && o.valid_per_frame % 8 == 0 && o.batch_stride % 8 == 0;
+    };
+    p.epi_lds = epi_lds_on && L.bf16 && unit_ok(a.out[0]) && (!two || (a.split % mo == 0 && unit_ok(a.out[1]))) &&
+                (L.epi == EPI_LINEAR || !two) && a.resid_batch_stride % 8 == 0;
     const long long n_max = (long long)a.Tmax * a.n_rows_per_frame + a.n_extra;
     if (n_max <= 0 || a.B <= 0) return MV_OK;
     dim3 grid((unsigned)((n_max + tc.NT() - 1) / tc.NT()), (unsigned)(L.M / tc.MT()), (unsigned)a.B);

@@ -1,6 +1,7 @@
 // waveglow.hip -- WaveGlow.infer (waveglow/glow.py:251-295 of the reference) on conv_cl_kernel.
 //
-// Data in HBM (float32, channels-last, L = 256*T/n_group time steps per sequence):
+// Data in HBM (channels-last, L = 256*T/n_group time steps per sequence; float32, except that in bf16 mode
+// SPECT, H, SKIP and ACTS can be stored as float16 with MV_WG_IO16=1):
 //   SPECT [B][L][n_mel*n_group]  upsampled + regrouped mel (glow.py:252-260); the transposed conv
 //                                is a 4-tap polyphase conv whose M order is permuted so that its
 //                                natural output [frame][phase*80+mel] IS [l][mel*n_group+g]
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256) void wg_noise_kernel(const float* __restrict__
 // glow.py:155: H = start(audio_0) (1x1, n_half -> C)
 __global__ __launch_bounds__(256) void wg_start_kernel(const float* __restrict__ aud, int ng, int off, int n_half,
                                                        const float* __restrict__ w, const float* __restrict__ bias,
-                                                       int C, int Cp, long long rows, float* __restrict__ H) {
+                                                       int C, int Cp, long long rows, void* __restrict__ H, int h16) {
     const int q = Cp / 4;  // float4 units per row
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= rows * q) return;
@@ -85,12 +86,12 @@ __global__ __launch_bounds__(256) void wg_start_kernel(const float* __restrict__
             v[i] = s + bias[c];
         }
     }
-    *(f32x4*)(H + r * Cp + c0) = v;
+    st4(H, r * Cp + c0, v, h16);
 }
 
 // glow.py:175 (end), 280-285 (coupling inverse, W^-1), 287-292 (early noise).  One wave per 16 steps:
 // lane = 16*part + step; the 4 parts split the channels of SKIP and are summed with two shuffles.
-__global__ __launch_bounds__(256) void wg_tail_kernel(const float* __restrict__ skip, int Cp, const float* __restrict__ end_w,
+__global__ __launch_bounds__(256) void wg_tail_kernel(const void* __restrict__ skip, int skip16, int Cp, const float* __restrict__ end_w,
                                                       const float* __restrict__ end_b, int n_half, int Ck,
                                                       const float* __restrict__ winv, float* __restrict__ aud, int ng,
                                                       const int32_t* __restrict__ lengths, int Tmax, int L,
@@ -112,9 +113,9 @@ __global__ __launch_bounds__(256) void wg_tail_kernel(const float* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
     if (valid) {
-        const f32x4* sr = (const f32x4*)(skip + ((long long)b * L + l) * Cp);
+        const long long se = ((long long)b * L + l) * Cp;
         for (int c4 = part; c4 < Cp / 4; c4 += 4) {
-            const f32x4 v = sr[c4];
+            const f32x4 v = ld4(skip, se + c4 * 4, skip16);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 if (j < nout) {
@@ -175,6 +176,11 @@ static void invert_small(const float* A, int n, float* out) {
     }
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) out[i * n + j] = (float)a[i * 2 * n + n + j];
+}
+
+static int env_or_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
 }
 
 static int expect(const HostTensor* t, std::initializer_list<int64_t> shape, const char* name) {
@@ -316,7 +322,10 @@ static int waveglow_build(WaveglowHandle* h, WeightMap& W) {
             sc.w = [=](int m, int, int ci) -> float { return cwd[(size_t)orig(m) * ncond + ci]; };
             std::vector<float> bias(2 * C);
             for (int m = 0; m < 2 * C; ++m) bias[m] = ib->data[orig(m)] + cbd[orig(m)];
-            if ((rc = build_layer(&f.in_layers[i], {sh, sc}, 2 * C, bias, bf16, EPI_GATE))) return rc;
+            // bf16: 256 x 128 tiles (a weight fragment feeds 8 MFMAs instead of 4: the L1 weight stream paces
+            // the 256 x 64 tile)
+            const int wide = bf16 && (2 * C) % 256 == 0 ? env_or_int("MV_WG_CFG", 1) : -1;
+            if ((rc = build_layer(&f.in_layers[i], {sh, sc}, 2 * C, bias, bf16, EPI_GATE, wide))) return rc;
             f.in_layers[i].alg_macs_per_n = (double)2 * C * C * ks + (double)2 * C * h->ncond;
 
             const int rsC = i < nl - 1 ? 2 * C : C;
@@ -333,7 +342,8 @@ static int waveglow_build(WaveglowHandle* h, WeightMap& W) {
             sa.dil = 1;
             sa.pad_left = 0;
             sa.w = [=](int m, int, int ci) -> float { return ci < C ? rwd[(size_t)m * C + ci] : 0.f; };
-            if ((rc = build_layer(&f.res_skip[i], {sa}, rsC, rb->data, bf16, EPI_LINEAR))) return rc;
+            const int rwide = bf16 && rsC % 256 == 0 ? env_or_int("MV_WG_CFG", 1) : -1;
+            if ((rc = build_layer(&f.res_skip[i], {sa}, rsC, rb->data, bf16, EPI_LINEAR, rwide))) return rc;
             f.res_skip[i].alg_macs_per_n = (double)rsC * C;
         }
         macs_step += (double)n_half * C + (double)h->ncond * 2 * C * nl + (double)nl * 2 * C * C * ks +
@@ -374,14 +384,16 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
     char* ws = (char*)workspace;
     float* X0 = (float*)ws;
     ws += WaveglowHandle::al((size_t)B * Tmax * h->melp * 4);
-    float* SPECT = (float*)ws;
+    void* SPECT = ws;
     ws += WaveglowHandle::al(bl * h->ncond * 4);
-    float* H = (float*)ws;
+    void* H = ws;
     ws += WaveglowHandle::al(bl * Cp * 4);
-    float* SKIP = (float*)ws;
+    void* SKIP = ws;
     ws += WaveglowHandle::al(bl * Cp * 4);
-    float* ACTS = (float*)ws;
+    void* ACTS = ws;
     ws += WaveglowHandle::al(bl * Cp * 4);
+    static const int io16_env = env_or_int("MV_WG_IO16", 0);  // measured slower than float32 storage at B = 1 (staging converts more than it saves)
+    const int io16 = h->precision == MV_PREC_BF16 && io16_env ? 1 : 0;
     float* AUDW = (float*)ws;
     // float output: the flow state lives directly in the caller's wav buffer
     float* AUD = out_format == MV_OUT_F32 ? (float*)wav : AUDW;
@@ -396,7 +408,7 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
         a.n_rows_per_frame = 1;
         a.n_extra = 3;
         const long long per_frame = (long long)spf * h->ncond;  // = 256 * n_mel
-        a.out[0] = ConvOut{SPECT, (long long)Tmax * per_frame, 0, per_frame, (int)per_frame, ACC_STORE};
+        a.out[0] = ConvOut{SPECT, (long long)Tmax * per_frame, 0, per_frame, (int)per_frame, ACC_STORE, io16};
         if ((rc = launch_layer(h->up, &sb, 1, a, stream, prof))) return rc;
     }
     {
@@ -413,19 +425,19 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
             const long long rows = (long long)B * L;
             const long long total = rows * (Cp / 4);
             hipLaunchKernelGGL(wg_start_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, AUD, ng,
-                               ng - f.Ck, f.n_half, f.start_w, f.start_b, h->C, Cp, rows, H);
+                               ng - f.Ck, f.n_half, f.start_w, f.start_b, h->C, Cp, rows, H, io16);
             MV_HIP(hipGetLastError());
         }
         for (int i = 0; i < nl; ++i) {
-            SrcBind sb[2] = {{H, bsC, Cp, spf, 1.0f}, {SPECT, (long long)L * h->ncond, h->ncond, spf, 1.0f}};
+            SrcBind sb[2] = {{H, bsC, Cp, spf, 1.0f, io16}, {SPECT, (long long)L * h->ncond, h->ncond, spf, 1.0f, io16}};
             LaunchArgs a;
             a.lengths = lengths;
             a.B = B;
             a.Tmax = Tmax;
             a.n_rows_per_frame = spf;
-            a.out[0] = ConvOut{ACTS, bsC, 0, (long long)spf * Cp, Cp, ACC_STORE};
+            a.out[0] = ConvOut{ACTS, bsC, 0, (long long)spf * Cp, Cp, ACC_STORE, io16};
             if ((rc = launch_layer(f.in_layers[i], sb, 2, a, stream, prof))) return rc;
-            SrcBind sa{ACTS, bsC, Cp, spf, 1.0f};
+            SrcBind sa{ACTS, bsC, Cp, spf, 1.0f, io16};
             LaunchArgs r;
             r.lengths = lengths;
             r.B = B;
@@ -434,10 +446,10 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
             const int skip_mode = i == 0 ? ACC_STORE : ACC_ADD;
             if (i < nl - 1) {
                 r.split = h->C;
-                r.out[0] = ConvOut{H, bsC, 0, (long long)spf * Cp, Cp, ACC_ADD};
-                r.out[1] = ConvOut{SKIP, bsC, 0, (long long)spf * Cp, Cp, skip_mode};
+                r.out[0] = ConvOut{H, bsC, 0, (long long)spf * Cp, Cp, ACC_ADD, io16};
+                r.out[1] = ConvOut{SKIP, bsC, 0, (long long)spf * Cp, Cp, skip_mode, io16};
             } else {
-                r.out[0] = ConvOut{SKIP, bsC, 0, (long long)spf * Cp, Cp, skip_mode};
+                r.out[0] = ConvOut{SKIP, bsC, 0, (long long)spf * Cp, Cp, skip_mode, io16};
             }
             if ((rc = launch_layer(f.res_skip[i], &sa, 1, r, stream, prof))) return rc;
         }
@@ -445,7 +457,7 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
         {
             dim3 grid((L + 63) / 64, B);
             const size_t lds = (size_t)2 * f.n_half * Cp * 4;
-            hipLaunchKernelGGL(wg_tail_kernel, grid, dim3(256), lds, stream, SKIP, Cp, f.end_w, f.end_b, f.n_half, f.Ck,
+            hipLaunchKernelGGL(wg_tail_kernel, grid, dim3(256), lds, stream, (const void*)SKIP, io16, Cp, f.end_w, f.end_b, f.n_half, f.Ck,
                                f.winv, AUD, ng, lengths, Tmax, L, spf, early ? noise[ni] : nullptr,
                                early ? c.n_early_size : 0, sigma);
             MV_HIP(hipGetLastError());
