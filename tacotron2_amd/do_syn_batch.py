@@ -9,7 +9,8 @@ of mels, length-bucketed and sharded by utterance over the ranks of one node.
 `synthetic-waveglow` (deterministic random weights, BASELINE.json config 4).  `--mels DIR` reads the
 reference's parameter files (16-byte int32 header frames, dim, num, den + float32 frames:
 README.md:14-17, do_syn.py:468-478); without it a synthetic corpus of 2-10 s mels is used.
-With `--out_dir` each utterance is written as mono 16-bit WAV (do_syn.py:285,394).
+With `--out_dir` each utterance is written as mono 16-bit WAV (do_syn.py:285,394); `--seg` adds the `.seg`
+label track and `--parameter_files` the vocoded frames in the reference's format (do_syn.py:286,396,466-478).
 One JSON line of gathered statistics is printed by rank 0; RCCL is used for that gather only.
 """
 from __future__ import annotations
@@ -22,23 +23,19 @@ import os
 import numpy as np
 import torch
 
-from . import batch, synth, vocoder
+from . import batch, outputs, synth, vocoder
 
 
 def read_parameter_file(path):
-    """[frames][dim] float32 behind a 4 x int32 header (frames, dim, num, den) -> mel [dim, frames]."""
+    """reference parameter file -> (mel [dim, frames], (num, den)); format in tacotron2_amd/outputs.py"""
     hdr = np.fromfile(path, dtype=np.int32, count=4)
-    frames, dim = int(hdr[0]), int(hdr[1])
-    x = np.fromfile(path, dtype=np.float32, offset=16, count=frames * dim).reshape(frames, dim)
-    return np.ascontiguousarray(x.T), (int(hdr[2]), int(hdr[3]))
+    frames, _ = outputs.read_parameter_file(path)
+    return np.ascontiguousarray(frames.T), (int(hdr[2]), int(hdr[3]))
 
 
 def write_parameter_file(path, mel, num=22050, den=256):
-    """Inverse of read_parameter_file (do_syn.py:468-478 writes (frames, dim, fe*?, ?) the same way)."""
-    mel = np.asarray(mel, np.float32)
-    with open(path, "wb") as f:
-        np.array([mel.shape[1], mel.shape[0], num, den], np.int32).tofile(f)
-        np.ascontiguousarray(mel.T).tofile(f)
+    """mel [dim, frames] -> reference parameter file at num/den frames per second"""
+    outputs.write_parameter_file(path, np.asarray(mel, np.float32).T, num / den)
 
 
 def build_vocoder(name, device, dtype):
@@ -74,6 +71,8 @@ def main(argv=None):
     ap.add_argument("--width", type=int, default=64, help="max frame spread inside a bucket")
     ap.add_argument("--out_dir", default=None)
     ap.add_argument("--fe_wav", type=int, default=22050)
+    ap.add_argument("--seg", action="store_true", help="with --out_dir: also write the .seg label track")
+    ap.add_argument("--parameter_files", action="store_true", help="with --out_dir: also write the frames (.WAVEGLOW)")
     args = ap.parse_args(argv)
 
     import torch.distributed as dist
@@ -105,7 +104,16 @@ def main(argv=None):
         os.makedirs(args.out_dir, exist_ok=True)
         for i, pcm in res.items():
             base = os.path.splitext(os.path.basename(names[i]))[0] if names else "utt%06d" % i
-            vocoder.write_wav(os.path.join(args.out_dir, base + ".wav"), pcm, args.fe_wav)
+            stem = os.path.join(args.out_dir, base)
+            if args.seg or args.parameter_files:
+                w = outputs.UtteranceWriter(stem, fe_wav=args.fe_wav, fe_data=args.fe_wav / voc.hop,
+                                            dim=mels[i].shape[0], parameter_file=args.parameter_files)
+                w.add_chunk(pcm, np.asarray(mels[i], np.float32).T, base)
+                w.close()
+                if not args.seg:
+                    os.remove(stem + ".seg")
+            else:
+                vocoder.write_wav(stem + ".wav", pcm, args.fe_wav)
     total = batch.gather_stats(st, dev)
     if rank == 0:
         print(json.dumps({
