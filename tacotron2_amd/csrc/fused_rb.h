@@ -376,13 +376,20 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
             if (io16x) {
                 // The A tile holds the window as raw float16 (rows outside the sequence are zeros).  Each lane
                 // takes its own fragments as the fp32 residual and leaves bf16(lrelu(x)) in their place.
+                // (all reads first: one LDS round trip for the lot instead of one per fragment)
+                unsigned long long rawq[TM][TN];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+                        rawq[tm][tn] = *(const unsigned long long*)(A0 + frag0 + tn * FRAG_TN + tm * FRAG_TM);
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
                     for (int tm = 0; tm < TM; ++tm) {
-                        unsigned long long* q = (unsigned long long*)(A0 + frag0 + tn * FRAG_TN + tm * FRAG_TM);
-                        X[tm][tn] = unpack4_f16(*q);
-                        *q = pack4_bf16(lrelu4(X[tm][tn], 0.1f));
+                        X[tm][tn] = unpack4_f16(rawq[tm][tn]);
+                        *(unsigned long long*)(A0 + frag0 + tn * FRAG_TN + tm * FRAG_TM) =
+                            pack4_bf16(lrelu4(X[tm][tn], 0.1f));
                     }
             } else {
 #pragma unroll
@@ -569,6 +576,7 @@ struct FusedStageParams {
     int io16;
     long long batch_stride;
     const int32_t* lengths;
+    int B;
     int Tmax;
     int rows_per_frame;
     int nrb;
@@ -598,28 +606,16 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
     constexpr int RS = C * 2 + kLdsRowPad;
     constexpr int NKC = C / 32;
     constexpr int PS = 9;  // floats per row of the conv_post partial table (7 taps, odd stride)
+    using WL = WinLoad<C, W, NTHREADS>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int cum_s[kMaxSeq + 1];
 
-    const int b = blockIdx.y;
-    const int len = (p.lengths ? p.lengths[b] : p.Tmax) * p.rows_per_frame;
-    const int out0 = blockIdx.x * p.NT;
+    // persistent block over the windows that exist (the host zero-fills the waveform beforehand: rows past a
+    // sequence's end are defined to be zero and no block visits them)
+    const int V = window_table(cum_s, p.lengths, p.B, p.Tmax, p.rows_per_frame, p.NT);
+    int v = blockIdx.x;
+    if (v >= V) return;
     const long long Lmax = (long long)p.Tmax * p.rows_per_frame;
-    if (out0 >= len) {
-        // the waveform past a sequence's end is defined to be zero
-        if (p.post_w) {
-            for (int i = threadIdx.x; i < p.NT; i += NTHREADS) {
-                const long long t = (long long)out0 + i;
-                if (t >= Lmax) break;
-                if (p.wav_pcm16)
-                    ((int16_t*)p.wav)[b * Lmax + t] = 0;
-                else
-                    ((float*)p.wav)[b * Lmax + t] = 0.f;
-            }
-        }
-        return;
-    }
-    const int t0 = out0 - p.H;
-    const bool interior = t0 >= 0 && t0 + W <= len;
     MV_TRACER(tr);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -628,8 +624,6 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
 
     char* A16 = smem;
     char* Y16 = smem + (W + 2 * p.guardA) * RS;
-    const void* xb = p.io16 ? (const void*)((const _Float16*)p.x + (long long)b * p.batch_stride)
-                            : (const void*)((const float*)p.x + (long long)b * p.batch_stride);
     {
         const int upr = RS / 16;
         for (int idx = threadIdx.x; idx < 2 * p.guardA * upr; idx += NTHREADS) {
@@ -649,206 +643,262 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
     constexpr int FRAG_TN = 16 * RS, FRAG_TM = 32;
     const int chq = (wm * TM) * 16 + lg * 4;
 
+    int b = find_seq(cum_s, p.B, v);
+    int len = (p.lengths ? p.lengths[b] : p.Tmax) * p.rows_per_frame;
+    int out0 = (v - cum_s[b]) * p.NT;
+    if (p.io16) {  // the block's first window arrives synchronously, every later one is prefetched
+        u32x4 raw[WL::PER];
+        issue_window16<C, W, NTHREADS>((const _Float16*)p.x + (long long)b * p.batch_stride, out0 - p.H, len, raw);
+        commit_raw16<C, W, NTHREADS>(raw, A0, RS);
+        __syncthreads();
+    }
+    MV_LAP(tr, TR_SETUP);
+
     f32x4 X[TM][TN], SUM[TM][TN], acc[TM][TN];
-    for (int j = 0; j < p.nrb; ++j) {
-        const int K = p.K[j];
-        const long long mtile_stride = (long long)K * NKC * 64;
-        const long long woff = (long long)(wm * TM) * mtile_stride + lane;
-        const int pad2 = (K - 1) / 2;
-        MV_LAP(tr, j == 0 ? TR_SETUP : TR_EPI);
-        if (j > 0) __syncthreads();  // every wave is done reading A16 / Y16 of the previous ResBlock
-        MV_LAP(tr, TR_BARRIER);
-        if (p.io16) {
-            load_window16<C, W, NTHREADS>((const _Float16*)xb, t0, len, A0, Y0, RS);
-            MV_LAP(tr, TR_LOADX);
-            __syncthreads();
-            MV_LAP(tr, TR_BARRIER);
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
-                    X[tm][tn] = unpack4_f16(*(const unsigned long long*)(Y0 + frag0 + tn * FRAG_TN + tm * FRAG_TM));
-        } else {
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                const int n = (wn * TN + tn) * 16 + lr;
-                const int g = t0 + n;
-                const bool in_seq = g >= 0 && g < len;
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm) {
-                    const int ch = (wm * TM + tm) * 16 + lg * 4;
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (in_seq) v = ld4(xb, (long long)g * C + ch, 0);
-                    X[tm][tn] = v;
-                    *(unsigned long long*)(A0 + n * RS + ch * 2) = pack4_bf16_lrelu(v, 0.1f, in_seq);
-                }
-            }
-            MV_LAP(tr, TR_LOADX);
-            __syncthreads();
-            MV_LAP(tr, TR_BARRIER);
+    for (;;) {
+        const int t0 = out0 - p.H;
+        const bool interior = t0 >= 0 && t0 + W <= len;
+        const void* xb = p.io16 ? (const void*)((const _Float16*)p.x + (long long)b * p.batch_stride)
+                                : (const void*)((const float*)p.x + (long long)b * p.batch_stride);
+        const int vn = v + (int)gridDim.x;
+        const bool has_next = vn < V;
+        int bn = 0, lenn = 0, out0n = 0;
+        if (has_next) {
+            bn = find_seq(cum_s, p.B, vn);
+            lenn = (p.lengths ? p.lengths[bn] : p.Tmax) * p.rows_per_frame;
+            out0n = (vn - cum_s[bn]) * p.NT;
         }
-        for (int m = 0; m < 3; ++m) {
-            const int d = p.dil[j][m];
-            const int pad1 = d * (K - 1) / 2;
-            if (m > 0) {
-                MV_LAP(tr, TR_EPI);
-                __syncthreads();
-                MV_LAP(tr, TR_BARRIER);
-            }
-            f32x4 bias[TM];
+        for (int j = 0; j < p.nrb; ++j) {
+            const int K = p.K[j];
+            const long long mtile_stride = (long long)K * NKC * 64;
+            const long long woff = (long long)(wm * TM) * mtile_stride + lane;
+            const int pad2 = (K - 1) / 2;
+            if (p.io16) {
+                // (every ResBlock restarts from the stage input: its rows were re-requested under the previous
+                // ResBlock's last conv1 epilogue and sit in the A tile as raw float16, like a new window's)
+                // raw float16 window in the A tile -> fp32 residual registers + bf16(lrelu) in place
+                // (all reads first: one LDS round trip for the lot instead of one per fragment)
+                unsigned long long rawq[TM][TN];
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) bias[tm] = *(const f32x4*)(p.b1[j][m] + chq + tm * 16);
-            conv_window<TM, TN>(acc, A0 + ((wn * TN * 16 + lr) - pad1) * RS + lg * 16, RS, K, d, NKC,
-                                (const u32x4*)p.w1[j][m] + woff, mtile_stride);
-            MV_LAP(tr, TR_KLOOP);
-            if (interior) {
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                    for (int tn = 0; tn < TN; ++tn)
-                        *(unsigned long long*)(Y0 + frag0 + tn * FRAG_TN + tm * FRAG_TM) =
-                            pack4_bf16(lrelu4(acc[tm][tn] + bias[tm], 0.1f));
-            } else {
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn) {
-                    const int g = t0 + (wn * TN + tn) * 16 + lr;
-                    const bool keep = g >= 0 && g < len;
+                for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
                     for (int tm = 0; tm < TM; ++tm)
-                        *(unsigned long long*)(Y0 + frag0 + tn * FRAG_TN + tm * FRAG_TM) =
-                            pack4_bf16_lrelu(acc[tm][tn] + bias[tm], 0.1f, keep);
-                }
-            }
-            MV_LAP(tr, TR_EPI);
-            __syncthreads();
-            MV_LAP(tr, TR_BARRIER);
+                        rawq[tm][tn] = *(const unsigned long long*)(A0 + frag0 + tn * FRAG_TN + tm * FRAG_TM);
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) bias[tm] = *(const f32x4*)(p.b2[j][m] + chq + tm * 16);
-            conv_window<TM, TN>(acc, Y0 + ((wn * TN * 16 + lr) - pad2) * RS + lg * 16, RS, K, 1, NKC,
-                                (const u32x4*)p.w2[j][m] + woff, mtile_stride);
-            MV_LAP(tr, TR_KLOOP);
+                for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                const int g = t0 + (wn * TN + tn) * 16 + lr;
-                const bool keep = interior || (g >= 0 && g < len);
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm) {
-                    X[tm][tn] = (acc[tm][tn] + bias[tm]) + X[tm][tn];
-                    if (m < 2)
+                    for (int tm = 0; tm < TM; ++tm) {
+                        X[tm][tn] = unpack4_f16(rawq[tm][tn]);
                         *(unsigned long long*)(A0 + frag0 + tn * FRAG_TN + tm * FRAG_TM) =
-                            pack4_bf16_lrelu(X[tm][tn], 0.1f, keep);
-                }
-            }
-        }
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) SUM[tm][tn] = j == 0 ? X[tm][tn] : SUM[tm][tn] + X[tm][tn];
-    }
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) SUM[tm][tn][i] = SUM[tm][tn][i] / p.div;
-
-    MV_LAP(tr, TR_EPI);
-    if (!p.post_w) {
-        if (p.io16) {
-            // A16 is free since the barrier before the last conv2: the mean leaves through it as float16
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
-                    *(unsigned long long*)(A0 + frag0 + tn * FRAG_TN + tm * FRAG_TM) = pack4_f16_sat(SUM[tm][tn]);
-            __syncthreads();
-            store_window16<C, NTHREADS>((_Float16*)p.out + (long long)b * p.batch_stride, A0, RS, t0, p.H, p.NT, len,
-                                        ACC_STORE, 1.f);
-        } else {
-            float* ob = (float*)p.out + (long long)b * p.batch_stride;
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm) {
-                const int ch = (wm * TM + tm) * 16 + lg * 4;
+                            pack4_bf16(lrelu4(X[tm][tn], 0.1f));
+                    }
+            } else {
+                if (j > 0 || v != (int)blockIdx.x) __syncthreads();  // every wave is done with the tiles
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) {
                     const int n = (wn * TN + tn) * 16 + lr;
                     const int g = t0 + n;
-                    if (n < p.H || n >= p.H + p.NT || g >= len) continue;
-                    st4(ob, (long long)g * C + ch, SUM[tm][tn], 0);
+                    const bool in_seq = g >= 0 && g < len;
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) {
+                        const int ch = (wm * TM + tm) * 16 + lg * 4;
+                        f32x4 q = {0.f, 0.f, 0.f, 0.f};
+                        if (in_seq) q = ld4(xb, (long long)g * C + ch, 0);
+                        X[tm][tn] = q;
+                        *(unsigned long long*)(A0 + n * RS + ch * 2) = pack4_bf16_lrelu(q, 0.1f, in_seq);
+                    }
                 }
             }
+            MV_LAP(tr, TR_LOADX);
+            __syncthreads();  // A16 complete
+            MV_LAP(tr, TR_BARRIER);
+            for (int m = 0; m < 3; ++m) {
+                const int d = p.dil[j][m];
+                const int pad1 = d * (K - 1) / 2;
+                if (m > 0) {
+                    MV_LAP(tr, TR_EPI);
+                    __syncthreads();
+                    MV_LAP(tr, TR_BARRIER);
+                }
+                f32x4 bias[TM];
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) bias[tm] = *(const f32x4*)(p.b1[j][m] + chq + tm * 16);
+                conv_window<TM, TN>(acc, A0 + ((wn * TN * 16 + lr) - pad1) * RS + lg * 16, RS, K, d, NKC,
+                                    (const u32x4*)p.w1[j][m] + woff, mtile_stride);
+                MV_LAP(tr, TR_KLOOP);
+                // Under the last conv1 epilogue of a ResBlock: request the rows the next ResBlock starts from -- the
+                // same window again (L2-hot), or the next window after the last ResBlock (see fused_rb_kernel).
+                const bool last_rb = j == p.nrb - 1;
+                const bool pf = p.io16 && m == 2 && (!last_rb || has_next);
+                u32x4 raw[WL::PER];
+                if (pf) {
+                    if (last_rb)
+                        issue_window16<C, W, NTHREADS>((const _Float16*)p.x + (long long)bn * p.batch_stride,
+                                                       out0n - p.H, lenn, raw);
+                    else
+                        issue_window16<C, W, NTHREADS>((const _Float16*)xb, t0, len, raw);
+                }
+                if (interior) {
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn)
+                            *(unsigned long long*)(Y0 + frag0 + tn * FRAG_TN + tm * FRAG_TM) =
+                                pack4_bf16(lrelu4(acc[tm][tn] + bias[tm], 0.1f));
+                } else {
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) {
+                        const int g = t0 + (wn * TN + tn) * 16 + lr;
+                        const bool keep = g >= 0 && g < len;
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm)
+                            *(unsigned long long*)(Y0 + frag0 + tn * FRAG_TN + tm * FRAG_TM) =
+                                pack4_bf16_lrelu(acc[tm][tn] + bias[tm], 0.1f, keep);
+                    }
+                }
+                MV_LAP(tr, TR_EPI);
+                __syncthreads();
+                MV_LAP(tr, TR_BARRIER);
+                if (pf) commit_raw16<C, W, NTHREADS>(raw, A0, RS);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) bias[tm] = *(const f32x4*)(p.b2[j][m] + chq + tm * 16);
+                conv_window<TM, TN>(acc, Y0 + ((wn * TN * 16 + lr) - pad2) * RS + lg * 16, RS, K, 1, NKC,
+                                    (const u32x4*)p.w2[j][m] + woff, mtile_stride);
+                MV_LAP(tr, TR_KLOOP);
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const int g = t0 + (wn * TN + tn) * 16 + lr;
+                    const bool keep = interior || (g >= 0 && g < len);
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) {
+                        X[tm][tn] = (acc[tm][tn] + bias[tm]) + X[tm][tn];
+                        if (m < 2)
+                            *(unsigned long long*)(A0 + frag0 + tn * FRAG_TN + tm * FRAG_TM) =
+                                pack4_bf16_lrelu(X[tm][tn], 0.1f, keep);
+                    }
+                }
+            }
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) SUM[tm][tn] = j == 0 ? X[tm][tn] : SUM[tm][tn] + X[tm][tn];
         }
-        MV_LAP(tr, TR_STORE);
-        MV_FLUSH(tr, (C << 16) | 0xff00 | p.nrb);
-        return;
-    }
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) SUM[tm][tn][i] = SUM[tm][tn][i] / p.div;
 
-    // ---- fused conv_post (models.py:161-163): y[t] = tanh(b + sum_k sum_c w[k][c] * lrelu(mean, 0.01)[t+k-3][c]).
-    // Pass 1, from registers: every lane dots its 4*TM channels of each of its rows with the 7 taps, the four
-    // lanes (lg) that share a row add up through ds_bpermute, and P[wm][n][k] lands in LDS (in the A tile,
-    // which no wave reads any more).  Pass 2: one output sample per thread sums 7*WM entries of P.
-    float* P = (float*)smem;  // [WM][W][PS]
-    {
-        f32x4 wk[7][TM];
+        MV_LAP(tr, TR_EPI);
+        // The result leaves through the Y tile (the A tile may already hold the next window).
+        __syncthreads();  // every wave is done reading Y16 as the last conv2's operand
+        MV_LAP(tr, TR_BARRIER);
+        if (!p.post_w) {
+            if (p.io16) {
 #pragma unroll
-        for (int k = 0; k < 7; ++k)
+                for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) wk[k][tm] = *(const f32x4*)(p.post_w + k * C + chq + tm * 16);
+                    for (int tm = 0; tm < TM; ++tm)
+                        *(unsigned long long*)(Y0 + frag0 + tn * FRAG_TN + tm * FRAG_TM) = pack4_f16_sat(SUM[tm][tn]);
+                MV_LAP(tr, TR_EPI);
+                __syncthreads();
+                MV_LAP(tr, TR_BARRIER);
+                store_window16<C, NTHREADS>((_Float16*)p.out + (long long)b * p.batch_stride, Y0, RS, t0, p.H, p.NT,
+                                            len, ACC_STORE, 1.f);
+            } else {
+                float* ob = (float*)p.out + (long long)b * p.batch_stride;
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int n = (wn * TN + tn) * 16 + lr;
-            const int g = t0 + n;
-            const bool keep = g >= 0 && g < len;
-            float part[7];
+                for (int tm = 0; tm < TM; ++tm) {
+                    const int ch = (wm * TM + tm) * 16 + lg * 4;
 #pragma unroll
-            for (int k = 0; k < 7; ++k) part[k] = 0.f;
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm) {
-                f32x4 v = lrelu4(SUM[tm][tn], 0.01f);
-                if (!keep) v = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int k = 0; k < 7; ++k) {
-                    part[k] += v[0] * wk[k][tm][0];
-                    part[k] += v[1] * wk[k][tm][1];
-                    part[k] += v[2] * wk[k][tm][2];
-                    part[k] += v[3] * wk[k][tm][3];
+                    for (int tn = 0; tn < TN; ++tn) {
+                        const int n = (wn * TN + tn) * 16 + lr;
+                        const int g = t0 + n;
+                        if (n < p.H || n >= p.H + p.NT || g >= len) continue;
+                        st4(ob, (long long)g * C + ch, SUM[tm][tn], 0);
+                    }
                 }
             }
+            MV_LAP(tr, TR_STORE);
+        } else {
+            // ---- fused conv_post (models.py:161-163): y[t] = tanh(b + sum_k sum_c w[k][c] * lrelu(mean, 0.01)[t+k-3][c]).
+            // Pass 1, from registers: every lane dots its 4*TM channels of each of its rows with the 7 taps, the
+            // four lanes (lg) that share a row add up through ds_bpermute, and P[wm][n][k] lands in LDS (in the Y
+            // tile).  Pass 2: one output sample per thread sums 7*WM entries of P.
+            float* P = (float*)Y0;  // [WM][W][PS], clear of the (zero) guard rows
+            {
+                f32x4 wk[7][TM];
 #pragma unroll
-            for (int k = 0; k < 7; ++k) {
-                part[k] += __shfl_xor(part[k], 16);
-                part[k] += __shfl_xor(part[k], 32);
+                for (int k = 0; k < 7; ++k)
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) wk[k][tm] = *(const f32x4*)(p.post_w + k * C + chq + tm * 16);
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const int n = (wn * TN + tn) * 16 + lr;
+                    const int g = t0 + n;
+                    const bool keep = g >= 0 && g < len;
+                    float part[7];
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) part[k] = 0.f;
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) {
+                        f32x4 q = lrelu4(SUM[tm][tn], 0.01f);
+                        if (!keep) q = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int k = 0; k < 7; ++k) {
+                            part[k] += q[0] * wk[k][tm][0];
+                            part[k] += q[1] * wk[k][tm][1];
+                            part[k] += q[2] * wk[k][tm][2];
+                            part[k] += q[3] * wk[k][tm][3];
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) {
+                        part[k] += __shfl_xor(part[k], 16);
+                        part[k] += __shfl_xor(part[k], 32);
+                    }
+                    // lane lg writes taps lg and lg + 4
+                    float* row = P + ((size_t)wm * W + n) * PS;
+                    const float lo = lg == 0 ? part[0] : lg == 1 ? part[1] : lg == 2 ? part[2] : part[3];
+                    const float hi = lg == 0 ? part[4] : lg == 1 ? part[5] : part[6];
+                    row[lg] = lo;
+                    if (lg < 3) row[lg + 4] = hi;
+                }
             }
-            // lane lg writes taps lg and lg + 4
-            float* row = P + ((size_t)wm * W + n) * PS;
-            const float lo = lg == 0 ? part[0] : lg == 1 ? part[1] : lg == 2 ? part[2] : part[3];
-            const float hi = lg == 0 ? part[4] : lg == 1 ? part[5] : part[6];
-            row[lg] = lo;
-            if (lg < 3) row[lg + 4] = hi;
-        }
-    }
-    __syncthreads();
-    const float bias = p.post_b[0];
-    for (int i = threadIdx.x; i < p.NT; i += NTHREADS) {
-        const int n = p.H + i;
-        const long long t = (long long)out0 + i;
-        if (t >= Lmax) break;
-        float y = 0.f;
-        if (t < len) {
-            float a = bias;
+            MV_LAP(tr, TR_POST);
+            __syncthreads();
+            MV_LAP(tr, TR_BARRIER);
+            const float bias = p.post_b[0];
+            for (int i = tid_here(); i < p.NT; i += NTHREADS) {
+                const int n = p.H + i;
+                const long long t = (long long)out0 + i;
+                if (t >= Lmax) break;
+                float y = 0.f;
+                if (t < len) {
+                    float a = bias;
 #pragma unroll
-            for (int k = 0; k < 7; ++k)
+                    for (int k = 0; k < 7; ++k)
 #pragma unroll
-                for (int w = 0; w < WM; ++w) a += P[((size_t)w * W + (n + k - 3)) * PS + k];
-            y = tanhf(a);
+                        for (int w = 0; w < WM; ++w) a += P[((size_t)w * W + (n + k - 3)) * PS + k];
+                    y = tanhf(a);
+                }
+                if (p.wav_pcm16)
+                    ((int16_t*)p.wav)[b * Lmax + t] = (int16_t)(int32_t)(32768.0f * y);
+                else
+                    ((float*)p.wav)[b * Lmax + t] = y;
+            }
+            MV_LAP(tr, TR_POST);
         }
-        if (p.wav_pcm16)
-            ((int16_t*)p.wav)[b * Lmax + t] = (int16_t)(int32_t)(32768.0f * y);
-        else
-            ((float*)p.wav)[b * Lmax + t] = y;
+        if (!has_next) break;
+        v = vn;
+        b = bn;
+        len = lenn;
+        out0 = out0n;
+        // io16: the barrier after the next window's in-place conversion separates these reads of the Y tile
+        // from the next conv1 epilogue that overwrites it; the fp32 path syncs at the top of the loop
     }
-    MV_LAP(tr, TR_POST);
-    MV_FLUSH(tr, (C << 16) | 0xfe00 | p.nrb);
+    MV_FLUSH(tr, (C << 16) | (p.post_w ? 0xfe00 : 0xff00) | p.nrb);
 }
 
 }  // namespace mv

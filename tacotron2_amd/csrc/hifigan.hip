@@ -68,7 +68,7 @@ static bool fuse_whole(const FusedCfg& fc, int K, const int* dils) {
     if (fc.npair < 3) return false;
     int H = 0;
     for (int m = 0; m < 3; ++m) H += (K - 1) / 2 * (dils[m] + 1);
-    static const int pct = env_or("MV_WHOLE_MIN_PCT", 55);  // NT / W at least this
+    static const int pct = env_or("MV_WHOLE_MIN_PCT", 70);  // NT / W at least this
     return (fc.W - 2 * H) * 100 >= fc.W * pct;
 }
 
@@ -434,6 +434,7 @@ static int launch_fused_stage(const StageCfg& sc, const HifiganHandle* h, int i,
     p.io16 = io16;
     p.batch_stride = bs;
     p.lengths = lengths;
+    p.B = B;
     p.Tmax = Tmax;
     p.rows_per_frame = rpf;
     p.nrb = c.num_kernels;
@@ -476,9 +477,12 @@ static int launch_fused_stage(const StageCfg& sc, const HifiganHandle* h, int i,
     const int RS = sc.C * 2 + kLdsRowPad;
     const size_t lds = (size_t)(2 * sc.W + 2 * gA + 2 * gY) * RS;
     static const int min_pct = env_or("MV_STAGE_MIN_PCT", 55);
-    if (lds > kFusedMaxLds || p.NT * 100 < sc.W * min_pct) return MV_EUNSUPPORTED;
+    if (lds > kFusedMaxLds || p.NT * 100 < sc.W * min_pct || B > kMaxSeq) return MV_EUNSUPPORTED;
     const long long rows = (long long)Tmax * rpf;
-    dim3 grid((unsigned)((rows + p.NT - 1) / p.NT), (unsigned)B);
+    const long long vmax = ((rows + p.NT - 1) / p.NT) * B;
+    dim3 grid((unsigned)std::min<long long>(vmax, cu_count()));
+    // the persistent blocks visit only windows that exist; the waveform past a sequence's end is zero
+    if (wav) MV_HIP(hipMemsetAsync(wav, 0, (size_t)B * rows * (out_format == MV_OUT_PCM16 ? 2 : 4), stream));
     if (prof) prof->begin(stream, wav ? std::string(sc.name) + "+conv_post" : std::string(sc.name), macs * rpf);
     hipLaunchKernelGGL(sc.k, grid, dim3(sc.threads), lds, stream, p);
     if (prof) prof->end(stream);
