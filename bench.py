@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dtype", default=os.environ.get("MELVOC_BENCH_DTYPE", "bf16"), choices=["bf16", "fp32"])
-    ap.add_argument("--model", default="hifigan", choices=["hifigan", "waveglow"])
+    ap.add_argument("--model", default="hifigan", choices=["hifigan", "waveglow", "postnet"])
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -126,6 +126,19 @@ def main():
         run = lambda: model(mel, lengths=lengths_d)  # noqa: E731
         workload = (f"HiFi-GAN V1 (config_v1), batch {args.batch} synthetic 80-bin mels of 2-10 s, one "
                     f"length-masked call per step")
+    elif args.model == "postnet":
+        # the Tacotron2 Postnet (+ input) of model.py:717 on the same batch of mels; its
+        # "audio seconds" are the seconds of speech the frames stand for (256 samples each)
+        from tacotron2_amd.postnet import Postnet
+
+        model = Postnet(synth.POSTNET_TC2, 0, precision=args.dtype)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.postnet_state(synth.POSTNET_TC2, 0).items()},
+                              strict=False)
+        model = model.eval().to(dev)
+        mel, lengths_d, lengths = make_batch(torch, args.batch, 1234 + rank, dev)
+        run = lambda: model(mel, lengths=lengths_d, add_input=True)  # noqa: E731
+        workload = (f"Tacotron2 Postnet (5 x Conv1d k5 512 ch + folded BatchNorm + tanh, + input), batch "
+                    f"{args.batch} synthetic 80-bin mels of 2-10 s")
     else:
         from tacotron2_amd.waveglow import WaveGlow
 

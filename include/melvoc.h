@@ -84,6 +84,15 @@ typedef struct mv_waveglow_cfg {
     int kernel_size;    /* WN_config.kernel_size 3 */
 } mv_waveglow_cfg;
 
+/* Postnet hyper-parameters of one decoder (model.py:146-168; tc2_french.yaml:15,87-89). */
+typedef struct mv_postnet_cfg {
+    int dim_data;        /* hps['dim_data'][i] 80 */
+    int embedding_dim;   /* hps['postnet_embedding_dim'][i] 512 */
+    int kernel_size;     /* hps['postnet_kernel_size'][i] 5 */
+    int n_convolutions;  /* hps['postnet_n_convolutions'][i] 5 */
+    float bn_eps;        /* nn.BatchNorm1d default 1e-5 */
+} mv_postnet_cfg;
+
 /* 1 = gfx950 HIP kernels.  (0 would be a CPU backend; this library has none.) */
 MV_API int mv_backend(void);
 
@@ -125,6 +134,20 @@ MV_API int mv_waveglow_create(const mv_waveglow_cfg* cfg, const mv_tensor* weigh
 MV_API int mv_waveglow_infer(mv_handle h, const float* mel, const int32_t* lengths, int B, int Tmax,
                       const float* const* noise, int n_noise, float sigma, void* wav, int out_format,
                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* Replaces: Postnet(hps, i_decoder) + load_state_dict + eval() + .to(device) (model.py:140-168,614-621).
+ * Weights by the module's state_dict keys: "convolutions.<i>.0.conv.weight|bias" and the BatchNorm1d tensors
+ * "convolutions.<i>.1.weight|bias|running_mean|running_var", folded into the conv here (eval mode; dropout
+ * is inactive in eval, model.py:172-173). */
+MV_API int mv_postnet_create(const mv_postnet_cfg* cfg, const mv_tensor* weights, int n_weights, int device,
+                      int precision, mv_handle* out);
+
+/* Replaces: Postnet.forward (model.py:170-174) and, with add_input != 0, the call site
+ * `par_out + self.postnet(par_out)` (model.py:717) whose result do_syn.py:380-391 hands to the vocoder.
+ *   x, y     device float32 [B][dim_data][Tmax] (the reference's layout); y may not alias x
+ *   lengths  device int32 [B] or NULL; frames past lengths[b] are written as 0 */
+MV_API int mv_postnet_forward(mv_handle h, const float* x, const int32_t* lengths, int B, int Tmax, float* y,
+                       int add_input, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Scratch bytes mv_*_forward/_infer need for a [B][*][Tmax] batch (either handle kind). */
 MV_API size_t mv_workspace_bytes(mv_handle h, int B, int Tmax);

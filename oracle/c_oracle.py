@@ -199,3 +199,27 @@ def pcm16(wav):
     out = np.empty(wav.shape, np.int16)
     lib().orc_pcm16(_fp(wav), C.c_size_t(wav.size), out.ctypes.data_as(C.POINTER(C.c_int16)))
     return out
+
+
+def postnet_forward(state, hps, x, add_input=False, bf16_operands=False, i_decoder=0, eps=1e-5):
+    """x [dim,T] (one sequence) -> [dim,T]: model.py:170-174 (+ :717) on orc_conv1d (double accumulation);
+    BatchNorm1d (eval) is applied in float64 after each conv, or folded first when modelling bf16 operands."""
+    n = hps["postnet_n_convolutions"][i_decoder]
+    k = hps["postnet_kernel_size"][i_decoder]
+    x0 = _f32(x)
+    y = x0
+    for i in range(n):
+        pre = "convolutions.%d" % i
+        w, b = np.asarray(state[pre + ".0.conv.weight"], np.float64), np.asarray(state[pre + ".0.conv.bias"], np.float64)
+        g, beta = np.asarray(state[pre + ".1.weight"], np.float64), np.asarray(state[pre + ".1.bias"], np.float64)
+        mu, var = np.asarray(state[pre + ".1.running_mean"], np.float64), np.asarray(state[pre + ".1.running_var"], np.float64)
+        s = g / np.sqrt(var + eps)
+        if bf16_operands:
+            y = conv1d(y, (w * s[:, None, None]).astype(np.float32), ((b - mu) * s + beta).astype(np.float32),
+                       1, (k - 1) // 2, True)
+        else:
+            c = conv1d(y, w.astype(np.float32), b.astype(np.float32), 1, (k - 1) // 2, False).astype(np.float64)
+            y = ((c - mu[:, None]) * s[:, None] + beta[:, None]).astype(np.float32)
+        if i < n - 1:
+            y = np.tanh(y.astype(np.float64)).astype(np.float32)
+    return (x0 + y) if add_input else y

@@ -17,6 +17,7 @@ Follows:
   waveglow_infer    waveglow/glow.py:251-295  (WaveGlow.infer), noise explicit
   _wn               waveglow/glow.py:153-175  (WN.forward)
   _gate             waveglow/glow.py:33-40    (fused_add_tanh_sigmoid_multiply)
+  postnet_forward   model.py:170-174,717      (Postnet.forward in eval mode, + input)
 """
 from __future__ import annotations
 
@@ -165,3 +166,36 @@ def pcm16(wav) -> np.ndarray:
     """do_syn.py:11,389-394: 32768*y -> host -> astype('int16') (truncate toward zero, no clip)."""
     a = (32768.0 * _t(wav)).cpu().numpy()
     return a.astype("int16")
+
+
+def postnet_forward(state, hps, x, add_input: bool = False, bf16_operands: bool = False, i_decoder: int = 0,
+                    eps: float = 1e-5):
+    """x [B,dim,T] or [dim,T] -> same shape (model.py:170-174): tanh(BN(conv(x))) n-1 times, then BN(conv(x));
+    BatchNorm1d in eval mode (running statistics), dropout inactive; add_input: model.py:717."""
+    q = _Q(bf16_operands)
+    w = {k: _t(v) for k, v in state.items()}
+    x0 = _t(x)
+    squeeze = x0.dim() == 2
+    if squeeze:
+        x0 = x0[None]
+    n = hps["postnet_n_convolutions"][i_decoder]
+    k = hps["postnet_kernel_size"][i_decoder]
+    y = x0
+    with torch.no_grad():
+        for i in range(n):
+            pre = f"convolutions.{i}"
+            if bf16_operands:
+                # the library folds BatchNorm into the conv before rounding the weights to bf16
+                s_ = w[pre + ".1.weight"] / torch.sqrt(w[pre + ".1.running_var"] + eps)
+                wf = w[pre + ".0.conv.weight"] * s_[:, None, None]
+                bf = (w[pre + ".0.conv.bias"] - w[pre + ".1.running_mean"]) * s_ + w[pre + ".1.bias"]
+                y = F.conv1d(q(y), q(wf), bf, padding=(k - 1) // 2)
+            else:
+                y = F.conv1d(y, w[pre + ".0.conv.weight"], w[pre + ".0.conv.bias"], padding=(k - 1) // 2)
+                y = F.batch_norm(y, w[pre + ".1.running_mean"], w[pre + ".1.running_var"], w[pre + ".1.weight"],
+                                 w[pre + ".1.bias"], training=False, eps=eps)
+            if i < n - 1:
+                y = torch.tanh(y)
+        if add_input:
+            y = x0 + y
+    return y[0] if squeeze else y

@@ -22,6 +22,7 @@ EXPORTS = (
     "mv_backend", "mv_last_error", "mv_hifigan_create", "mv_hifigan_forward", "mv_waveglow_create",
     "mv_waveglow_infer", "mv_workspace_bytes", "mv_hop", "mv_macs_per_frame", "mv_destroy", "mv_pcm16",
     "mv_test_conv1d", "mv_test_conv_transpose1d", "mv_profile_begin", "mv_profile_end",
+    "mv_postnet_create", "mv_postnet_forward",
 )
 
 
@@ -57,6 +58,11 @@ class mv_waveglow_cfg(C.Structure):
         ("n_channels", C.c_int),
         ("kernel_size", C.c_int),
     ]
+
+
+class mv_postnet_cfg(C.Structure):
+    _fields_ = [("dim_data", C.c_int), ("embedding_dim", C.c_int), ("kernel_size", C.c_int),
+                ("n_convolutions", C.c_int), ("bn_eps", C.c_float)]
 
 
 class mv_profile_row(C.Structure):
@@ -95,6 +101,8 @@ def lib():
     l.mv_hifigan_forward.argtypes = [vp, vp, vp, i32, i32, vp, i32, vp, C.c_size_t, vp]
     l.mv_waveglow_create.argtypes = [C.POINTER(mv_waveglow_cfg), C.POINTER(mv_tensor), i32, i32, i32, C.POINTER(vp)]
     l.mv_waveglow_infer.argtypes = [vp, vp, vp, i32, i32, C.POINTER(vp), i32, C.c_float, vp, i32, vp, C.c_size_t, vp]
+    l.mv_postnet_create.argtypes = [C.POINTER(mv_postnet_cfg), C.POINTER(mv_tensor), i32, i32, i32, C.POINTER(vp)]
+    l.mv_postnet_forward.argtypes = [vp, vp, vp, i32, i32, vp, i32, vp, C.c_size_t, vp]
     l.mv_workspace_bytes.argtypes = [vp, i32, i32]
     l.mv_workspace_bytes.restype = C.c_size_t
     l.mv_hop.argtypes = [vp]
@@ -218,3 +226,11 @@ def create_waveglow(cfg, state, device_index: int, precision: int) -> Handle:
     check(lib().mv_waveglow_create(C.byref(c), arr, len(keep), int(device_index), int(precision), C.byref(out)),
           "mv_waveglow_create")
     return Handle(out.value, "waveglow")
+
+
+def create_postnet(cfg: mv_postnet_cfg, state, device_index: int, precision: int) -> Handle:
+    arr, keep = make_tensors(state)
+    out = C.c_void_p()
+    check(lib().mv_postnet_create(C.byref(cfg), arr, len(keep), int(device_index), int(precision), C.byref(out)),
+          "mv_postnet_create")
+    return Handle(out.value, "postnet")

@@ -110,6 +110,7 @@ struct LaunchArgs {
     const void* resid = nullptr;  // typed like out[0]
     long long resid_batch_stride = 0;
     float div = 1.f;
+    int act = 0;  // 1: tanh on the linear epilogue
 };
 
 int launch_layer(const Layer& L, const SrcBind* srcs, int nsrc, const LaunchArgs& a, hipStream_t stream,
@@ -131,6 +132,10 @@ class WeightMap {
    private:
     std::map<std::string, HostTensor> m_;
 };
+
+// Conv1d [Cout][Cin][K] as a layer, channels zero-padded to cin_pad / cout_pad (hifigan.hip)
+int build_conv1d_layer(Layer* L, const HostTensor* w, const HostTensor* b, int Cin, int Cout, int K, int dil,
+                       int cin_pad, int cout_pad, bool bf16, int force_cfg = -1);
 
 template <typename T>
 int upload(const std::vector<T>& host, T** dev) {

@@ -76,6 +76,7 @@ struct ConvParams {
     const void* resid;   // optional, indexed (and typed) like out[0]
     long long resid_batch_stride;
     float div;           // ACC_ADD_DIV divisor
+    int act;             // linear epilogue: 0 = none, 1 = tanh(acc + bias) before residual / accumulate (model.py:172)
     int epi_lds;         // linear epilogue, one float16 output: leave through LDS with 16-byte coalesced stores
 };
 
@@ -279,6 +280,9 @@ __device__ __forceinline__ void mma_pass(f32x4 (&acc)[TM][TN], const char* lds_b
         for (int tm = 0; tm < TM; ++tm) {
 #if defined(MV_ABLATE) && (MV_ABLATE & 4)
             a[tm] = u32x4{(unsigned)sn, 0u, 0u, 0u};  // timing-only build: no weight loads
+#elif defined(MV_ABLATE) && (MV_ABLATE & 32)
+            // timing-only build: weight fragments read from LDS (garbage) instead of L2
+            a[tm] = *(const u32x4*)(lds_b + ((sn & 3) * 4 + tm) * 1024 + (threadIdx.x & 63) * 16 - (size_t)0);
 #else
             a[tm] = wlane[tm * mtile_stride + (long long)sn * 64];
 #endif
@@ -415,7 +419,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_cl_kernel(const ConvParams p
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn) {
                         const int nl = (wn * TN + tn) * 16 + lr;
-                        const f32x4 v = acc[tm][tn] + bias;
+                        f32x4 v = acc[tm][tn] + bias;
+                        if (p.act == 1) v = f32x4{tanhf(v[0]), tanhf(v[1]), tanhf(v[2]), tanhf(v[3])};
                         f16x4 h;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) h[i] = (_Float16)fminf(fmaxf(v[i], -65504.f), 65504.f);
@@ -524,7 +529,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_cl_kernel(const ConvParams p
                 const int n = n0 + (wn * TN + tn) * 16 + lr;
                 if (n >= n_ext) continue;
                 const long long e = (long long)n * o.row_stride + m + o.off;
-                store_out(o, b, e, valid, acc[tm][tn] + bias, oi ? nullptr : resid_b, p.div);
+                f32x4 v = acc[tm][tn] + bias;
+                if (p.act == 1) v = f32x4{tanhf(v[0]), tanhf(v[1]), tanhf(v[2]), tanhf(v[3])};
+                store_out(o, b, e, valid, v, oi ? nullptr : resid_b, p.div);
             }
         }
     } else {

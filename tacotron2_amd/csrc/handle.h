@@ -3,7 +3,7 @@
 #include "common.h"
 
 struct mv_handle_s {
-    int kind = 0;  // 1 = HiFi-GAN generator, 2 = WaveGlow
+    int kind = 0;  // 1 = HiFi-GAN generator, 2 = WaveGlow, 3 = Tacotron2 Postnet
     int device = 0;
     int precision = MV_PREC_FP32;
     mv::Profiler prof;

@@ -205,7 +205,7 @@ static int bias_check(const HostTensor* b, int64_t n, const char* name) {
 
 // Conv1d [Cout][Cin][K] as a layer; output/ input channels padded with zeros.
 int build_conv1d_layer(Layer* L, const HostTensor* w, const HostTensor* b, int Cin, int Cout, int K, int dil,
-                       int cin_pad, int cout_pad, bool bf16, int force_cfg = -1) {
+                       int cin_pad, int cout_pad, bool bf16, int force_cfg) {
     const float* wd = w->data.data();
     SrcSpec s;
     s.C = cin_pad;

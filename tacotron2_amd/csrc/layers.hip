@@ -286,6 +286,7 @@ int launch_layer(const Layer& L, const SrcBind* srcs, int nsrc, const LaunchArgs
     p.resid = a.resid;
     p.resid_batch_stride = a.resid_batch_stride;
     p.div = a.div;
+    p.act = a.act;
     static const int epi_lds_on = env_int("MV_EPI_LDS", 1);
     // the coalescing epilogue (conv_cl_kernel) wants 8-element units that never straddle a validity bound, a
     // block's M range on one side of the split, and a residual typed and laid out like out[0]

@@ -245,3 +245,28 @@ def waveglow_noise(cfg, B: int, T: int, seed: int = 1234):
         if k % cfg["n_early_every"] == 0 and k > 0:
             out.append(rng.standard_normal((B, cfg["n_early_size"], L)).astype(np.float32))
     return out
+
+
+# ---- Tacotron2 Postnet (model.py:140-174; tc2_french.yaml:15,66,87-89) ---------------------------
+POSTNET_TC2 = {"dim_data": [80], "postnet_embedding_dim": [512], "postnet_kernel_size": [5],
+               "postnet_n_convolutions": [5], "p_postnet_dropout": [0.5]}
+
+
+def postnet_state(hps=POSTNET_TC2, seed: int = 0, i_decoder: int = 0):
+    """Deterministic Postnet state_dict (the reference's key names): fan-in-scaled conv weights, non-trivial
+    BatchNorm affine parameters and running statistics so that the eval-mode folding is exercised."""
+    rng = np.random.default_rng(seed)
+    dim, emb = hps["dim_data"][i_decoder], hps["postnet_embedding_dim"][i_decoder]
+    k, n = hps["postnet_kernel_size"][i_decoder], hps["postnet_n_convolutions"][i_decoder]
+    out = OrderedDict()
+    for i in range(n):
+        cin, cout = (dim if i == 0 else emb), (dim if i == n - 1 else emb)
+        gain = 1.0 if i == n - 1 else 5.0 / 3.0
+        out[f"convolutions.{i}.0.conv.weight"] = (gain / math.sqrt(cin * k) *
+                                                  rng.standard_normal((cout, cin, k))).astype(np.float32)
+        out[f"convolutions.{i}.0.conv.bias"] = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+        out[f"convolutions.{i}.1.weight"] = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+        out[f"convolutions.{i}.1.bias"] = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+        out[f"convolutions.{i}.1.running_mean"] = (0.2 * rng.standard_normal(cout)).astype(np.float32)
+        out[f"convolutions.{i}.1.running_var"] = rng.uniform(0.5, 2.0, cout).astype(np.float32)
+    return out

@@ -14,6 +14,7 @@ Reference entry points exercised:
                              Invertible1x1Conv reverse) walked as infer() does at
                              glow.py:251-295 with explicit noise, because infer()
                              itself allocates torch.cuda tensors (glow.py:262-269)
+  model.py:140-174,717       Postnet (eval mode) and the sum with its input
 """
 import copy
 import json
@@ -217,8 +218,30 @@ def pcm_case(name):
     print(name, pcm[:8])
 
 
+def postnet_case(name, hps, seed, lengths, mel_seed):
+    """model.py:140-174 Postnet in eval mode on each sequence alone (batch 1), and model.py:717's sum."""
+    import model  # the reference's model.py
+
+    ref = model.Postnet(hps, 0)
+    st = synth.postnet_state(hps, seed)
+    missing = ref.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()}, strict=False)
+    assert all(k.endswith("num_batches_tracked") for k in missing.missing_keys) and not missing.unexpected_keys
+    ref.eval()
+    out = {"lengths": np.asarray(lengths, np.int32), "seed": np.int32(seed), "mel_seed": np.int32(mel_seed)}
+    for i, T in enumerate(lengths):
+        x = torch.from_numpy(synth.synthetic_mel(int(T), mel_seed + i))[None]
+        y = ref(x)
+        out[f"post.{i}"] = y[0].numpy()
+        out[f"sum.{i}"] = (x + y)[0].numpy()
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(name, {k: v.shape for k, v in out.items() if k.startswith("post")})
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    if "--only-postnet" in sys.argv:
+        postnet_case("postnet_tc2_ragged", synth.POSTNET_TC2, 0, [40, 52, 64], 4321)
+        return
     v1 = json.load(open(os.path.join(REF, "hifigan", "config.json")))
     hifigan_case("hifigan_v1_T64", v1, 0, 64, 1234)
     hifigan_case("hifigan_v1_T500", v1, 0, 500, 1234)
@@ -236,6 +259,7 @@ def main():
     waveglow_case("waveglow_c256_T64", wg256, 0, 64, 1, 1234, 1234, 0.666)
     pcm_case("pcm16_v1_T64")
     waveglow_pickle_case("waveglow_tiny_ref")
+    postnet_case("postnet_tc2_ragged", synth.POSTNET_TC2, 0, [40, 52, 64], 4321)
 
 
 if __name__ == "__main__":

@@ -163,3 +163,17 @@ def test_bf16_operand_model_meets_snr():
     b = c_oracle.hifigan_forward(st, synth.HIFIGAN_V1, mel, bf16_operands=True)
     snr = 10 * np.log10((a.astype(np.float64) ** 2).sum() / ((a - b).astype(np.float64) ** 2).sum())
     assert snr >= 40.0, snr
+
+
+def test_postnet_oracles_match_reference(golden_dir):
+    """model.py:140-174,717 (eval mode) captured from the real reference Postnet, per sequence."""
+    d = _load(golden_dir, "postnet_tc2_ragged")
+    st = synth.postnet_state(synth.POSTNET_TC2, int(d["seed"]))
+    for i, T in enumerate(d["lengths"]):
+        x = synth.synthetic_mel(int(T), int(d["mel_seed"]) + i)
+        y = c_oracle.postnet_forward(st, synth.POSTNET_TC2, x)
+        assert np.abs(y - d[f"post.{i}"]).max() < TOL
+        s = c_oracle.postnet_forward(st, synth.POSTNET_TC2, x, add_input=True)
+        assert np.abs(s - d[f"sum.{i}"]).max() < TOL
+        t = torch_ref.postnet_forward(st, synth.POSTNET_TC2, x, add_input=True).numpy()
+        assert np.abs(t - d[f"sum.{i}"]).max() < TOL
