@@ -226,8 +226,14 @@ __device__ __forceinline__ void load_bgroup(u32x4 (&q)[G], const char* bp, int R
 
 // One K step.  PAR = which of the two buffers holds this step's group 0 on entry; on exit the next
 // step's group 0 (read through bp_next) sits in buffer (PAR + NG) & 1.
+#if defined(MV_ABLATE) && (MV_ABLATE & 64)
+#define MV_XA 1  // timing-only build: one extra L2-loaded fragment per K step rides along (stands for an LDS fill)
+#else
+#define MV_XA 0
+#endif
+
 template <bool BF16, int TM, int TN, int PAR>
-__device__ __forceinline__ void mma_step(f32x4 (&acc)[TM][TN], const u32x4 (&a)[TM], const char* bp,
+__device__ __forceinline__ void mma_step(f32x4 (&acc)[TM][TN], const u32x4 (&a)[TM + MV_XA], const char* bp,
                                          const char* bp_next, int RS, u32x4 (&q0)[BPipe<TM, TN>::G],
                                          u32x4 (&q1)[BPipe<TM, TN>::G]) {
     constexpr int G = BPipe<TM, TN>::G, NG = BPipe<TM, TN>::NG;
@@ -248,6 +254,9 @@ __device__ __forceinline__ void mma_step(f32x4 (&acc)[TM][TN], const u32x4 (&a)[
         // pin the order: hipcc otherwise sinks every ds_read to just before its MFMA (lgkmcnt(0)
         // after each read), which exposes the full LDS latency at one wave per SIMD
         __builtin_amdgcn_sched_barrier(0);
+#if MV_XA
+        if (g == 0) asm volatile("" ::"v"(a[TM]));
+#endif
         __builtin_amdgcn_s_setprio(kMfmaPrio);
 #pragma unroll
         for (int j = 0; j < G; ++j) {
@@ -272,10 +281,25 @@ __device__ __forceinline__ void mma_pass(f32x4 (&acc)[TM][TN], const char* lds_b
     constexpr int P1 = NG & 1;  // buffer parity of the 2nd / 4th step of an unrolled group
     const int S = ktaps * nkc;
     const int tap_wrap = dil * RS - nkc * 64;
-    u32x4 a0[TM], a1[TM], a2[TM], a3[TM];
+    u32x4 a0[TM + MV_XA], a1[TM + MV_XA], a2[TM + MV_XA], a3[TM + MV_XA];
     u32x4 q0[G], q1[G];
-    auto fetch = [&](u32x4 (&a)[TM], int step) {
+    // Weight fragments come through buffer loads: the wave-uniform part of the address (every lane of a wave
+    // reads the same M tiles) sits in a scalar buffer descriptor + scalar offset, the lane part is one 32-bit
+    // VGPR, so stepping through K costs scalar adds only (global_load took two 64-bit VALU adds per fragment,
+    // issued between the MFMAs).
+    const unsigned lane_off = (threadIdx.x & 63u) * 16u;
+    const unsigned long long wu = (unsigned long long)(wlane - (threadIdx.x & 63u));
+    // (readfirstlane returns int: go through unsigned, or the low half sign-extends into the high half)
+    const unsigned w_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(wu >> 32));
+    const unsigned w_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wu);
+    void* wbase = (void*)(((unsigned long long)w_hi << 32) | (unsigned long long)w_lo);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(wbase, 0, 0x7fffffff, 0x00020000);
+    const int mtile_bytes = (int)(mtile_stride * 16);
+    auto fetch = [&](u32x4 (&a)[TM + MV_XA], int step) {
         const int sn = step < S ? step : S - 1;
+#if MV_XA
+        a[TM] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_off, sn * 1024, 0);
+#endif
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
 #if defined(MV_ABLATE) && (MV_ABLATE & 4)
@@ -284,7 +308,7 @@ __device__ __forceinline__ void mma_pass(f32x4 (&acc)[TM][TN], const char* lds_b
             // timing-only build: weight fragments read from LDS (garbage) instead of L2
             a[tm] = *(const u32x4*)(lds_b + ((sn & 3) * 4 + tm) * 1024 + (threadIdx.x & 63) * 16 - (size_t)0);
 #else
-            a[tm] = wlane[tm * mtile_stride + (long long)sn * 64];
+            a[tm] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_off, tm * mtile_bytes + sn * 1024, 0);
 #endif
         }
     };
