@@ -100,32 +100,119 @@ class ShardStats:
         return ShardStats(int(v[0]), int(v[1]), int(v[2]), v[3], v[4], int(v[5]), v[6])
 
 
+def device_mel_bucket(bucket, seed, device, n_mels=80, pad_value=synth.MEL_PAD_VALUE):
+    """BASELINE.json config 4: the bucket's mels generated ON the device from one seed per utterance
+    (clip(N(-5, 2^2), pad, 2.5) like synth.synthetic_mel), so no mel crosses PCIe."""
+    B, tmax = len(bucket.indices), bucket.tmax
+    x = torch.full((B, n_mels, tmax), float(pad_value), dtype=torch.float32, device=device)
+    g = torch.Generator(device=device)
+    for b, (i, T) in enumerate(zip(bucket.indices, bucket.lengths)):
+        g.manual_seed(int(seed) * 100003 + int(i))
+        x[b, :, :T] = torch.empty((n_mels, T), dtype=torch.float32, device=device).normal_(-5.0, 2.0, generator=g) \
+            .clamp_(float(pad_value), 2.5)
+    return x, torch.tensor(bucket.lengths, dtype=torch.int32)
+
+
 def synthesize_shard(vocoder, mels, lengths=None, rank=0, world=1, device=None, fe_wav=22050, hop=256,
-                     max_batch=32, width=64, max_frames=32 * 1024, keep_audio=True, out="pcm16"):
+                     max_batch=32, width=64, max_frames=32 * 1024, keep_audio=True, out="pcm16", pipeline=True,
+                     device_mels=None, d2h=True):
     """Vocode this rank's share of `mels` (list of [80,T]).  Returns ({utterance index: int16 / float
-    numpy waveform}, ShardStats).  `vocoder(mel[B,80,T], lengths=int32[B], out=...) -> [B, hop*T]`."""
+    numpy waveform}, ShardStats).  `vocoder(mel[B,80,T], lengths=int32[B], out=...) -> [B, hop*T]`.
+
+    On a GPU the loop is a three-stage pipeline: a host thread pads bucket k+1 into pinned memory while the
+    copy-in stream uploads bucket k, the compute stream vocodes it, and the copy-out stream drains bucket k-1
+    into pinned memory (do_syn.py:380-394 does these strictly one after the other).  `device_mels=seed`
+    generates the mels on the device instead (config 4); `d2h=False` leaves the audio on the device (then nothing
+    is returned).  The checksum (sum |sample|) is accumulated on the device and read once at the end."""
     if lengths is None:
         lengths = [int(m.shape[1]) for m in mels]
     buckets = make_buckets(lengths, max_batch, width, max_frames)
     shards, _ = shard_buckets(buckets, world)
+    mine = shards[rank]
     stats = ShardStats(rank=rank)
     results = {}
-    sync = torch.cuda.synchronize if (device is not None and torch.device(device).type == "cuda") else (lambda: None)
+    on_gpu = device is not None and torch.device(device).type == "cuda"
+    sync = torch.cuda.synchronize if on_gpu else (lambda: None)
     sync()
     t0 = time.perf_counter()
-    for bi in shards[rank]:
-        bk = buckets[bi]
-        x, lens = pad_bucket(mels, bk, device=device)
-        wav = vocoder(x, lengths=lens, out=out)
-        stats.calls += 1
-        host = wav.cpu().numpy()  # the D->H copy is part of the driver's work (do_syn.py:393)
-        for b, (i, T) in enumerate(zip(bk.indices, bk.lengths)):
-            a = host[b, : T * hop]
-            stats.checksum += float(np.abs(a.astype(np.float64)).sum())
+    if not (pipeline and on_gpu):
+        for bi in mine:
+            bk = buckets[bi]
+            x, lens = pad_bucket(mels, bk, device=device)
+            wav = vocoder(x, lengths=lens, out=out)
+            stats.calls += 1
+            host = wav.cpu().numpy()  # the D->H copy is part of the driver's work (do_syn.py:393)
+            for b, (i, T) in enumerate(zip(bk.indices, bk.lengths)):
+                a = host[b, : T * hop]
+                stats.checksum += float(np.abs(a.astype(np.float64)).sum())
+                if keep_audio:
+                    results[i] = a.copy()
+            stats.utterances += len(bk.indices)
+            stats.frames += bk.cost
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+
+        dev = torch.device(device)
+        compute = torch.cuda.current_stream(dev)
+        copy_in, copy_out = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        pool = ThreadPoolExecutor(1)
+        csum = torch.zeros((), dtype=torch.float64, device=dev)
+        odt = torch.int16 if out == "pcm16" else torch.float32
+        cap = max((len(buckets[bi].indices) * buckets[bi].tmax for bi in mine), default=0) * hop
+        slots = [torch.empty(cap, dtype=odt).pin_memory() for _ in range(2)] if (d2h and cap) else []
+
+        def prep(bi):
+            if device_mels is not None:
+                return None
+            x, lens = pad_bucket(mels, buckets[bi])
+            return x.pin_memory(), lens
+
+        def finalize(p):
+            if p is None:
+                return
+            bk, hb, ev = p
+            ev.synchronize()
             if keep_audio:
-                results[i] = a.copy()
-        stats.utterances += len(bk.indices)
-        stats.frames += bk.cost
+                host = hb.numpy()
+                for b, (i, T) in enumerate(zip(bk.indices, bk.lengths)):
+                    results[i] = host[b, : T * hop].copy()
+
+        fut = pool.submit(prep, mine[0]) if mine else None
+        pending = None
+        for k, bi in enumerate(mine):
+            bk = buckets[bi]
+            staged = fut.result()
+            if k + 1 < len(mine):
+                fut = pool.submit(prep, mine[k + 1])
+            if device_mels is not None:
+                x, lens = device_mel_bucket(bk, device_mels, dev)
+            else:
+                xh, lens = staged
+                with torch.cuda.stream(copy_in):
+                    x = xh.to(dev, non_blocking=True)
+                    ev_in = copy_in.record_event()
+                compute.wait_event(ev_in)
+                x.record_stream(compute)
+            wav = vocoder(x, lengths=lens, out=out)
+            stats.calls += 1
+            csum += wav.to(torch.float32).abs().sum(dtype=torch.float64)
+            if d2h:
+                ev_c = compute.record_event()
+                B, n = wav.shape[0], wav.shape[-1]
+                hb = slots[k & 1][: B * n].view(B, n)
+                finalize(pending)  # bucket k-1 is on the host: its slot is the one bucket k+1 will reuse
+                with torch.cuda.stream(copy_out):
+                    copy_out.wait_event(ev_c)
+                    hb.copy_(wav.view(B, n), non_blocking=True)
+                    wav.record_stream(copy_out)
+                    ev_o = copy_out.record_event()
+                pending = (bk, hb, ev_o)
+            stats.utterances += len(bk.indices)
+            stats.frames += bk.cost
+        finalize(pending)
+        pool.shutdown()
+        sync()
+        stats.checksum = float(csum.item())
     sync()
     stats.wall_seconds = time.perf_counter() - t0
     stats.audio_seconds = stats.frames * hop / float(fe_wav)
