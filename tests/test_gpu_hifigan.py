@@ -128,3 +128,38 @@ def test_errors_are_loud(gen_fp32):
         gen_fp32(torch.zeros(1, 79, 8, device="cuda"))
     with pytest.raises(RuntimeError):
         gen_fp32(torch.zeros(2, 80, 8, device="cuda"), lengths=[9, 1])
+
+
+def test_edge_lengths_bf16_fused_kernels(gen_bf16):
+    """The persistent fused kernels walk only the windows that exist: empty and one-frame sequences, a batch wider
+    than the bench's, unsorted lengths, and the zero fill past each sequence's end (float and PCM16 outputs)."""
+    st = synth.hifigan_state(synth.HIFIGAN_V1, 0)
+
+    def snr(ref, got):
+        return 10 * np.log10(np.sum(ref.astype(np.float64) ** 2) / max(np.sum((ref - got).astype(np.float64) ** 2), 1e-30))
+
+    mel1 = synth.synthetic_mel(1, 9)
+    y1 = gen_bf16(torch.from_numpy(mel1).cuda())[0].cpu().numpy()
+    assert snr(c_oracle.hifigan_forward(st, synth.HIFIGAN_V1, mel1, bf16_operands=True), y1) >= 40.0
+
+    rng = np.random.default_rng(5)
+    lens = [0, 7, 1, 333, 2] + [int(t) for t in rng.integers(1, 120, size=35)]
+    T = max(lens)
+    x = torch.full((len(lens), 80, T), synth.MEL_PAD_VALUE)
+    for b, n in enumerate(lens):
+        if n:
+            x[b, :, :n] = torch.from_numpy(synth.synthetic_mel(n, 100 + b))
+    xg = x.cuda()
+    y = gen_bf16(xg, lengths=lens)[:, 0].cpu().numpy()
+    p = gen_bf16(xg, lengths=lens, out="pcm16")[:, 0].cpu().numpy()
+    for b, n in enumerate(lens):
+        assert not y[b, n * 256:].any() and not p[b, n * 256:].any()
+        if n == 0:
+            continue
+        if b in (1, 2, 3, 4, 7, 21, 39):
+            solo = gen_bf16(xg[b:b + 1, :, :n].contiguous())[0, 0].cpu().numpy()
+            # same inputs reach every sample; only the window a sample falls in differs between the calls
+            assert np.abs(solo - y[b, :n * 256]).max() <= 2e-3
+            assert np.array_equal(p[b, :n * 256], c_oracle.pcm16(y[b, :n * 256]))
+    ref = c_oracle.hifigan_forward(st, synth.HIFIGAN_V1, synth.synthetic_mel(333, 103), bf16_operands=True)
+    assert snr(ref, y[3, :333 * 256]) >= 40.0
