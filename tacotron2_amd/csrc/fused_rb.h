@@ -110,6 +110,15 @@ __device__ __forceinline__ void conv_window(f32x4 (&acc)[TM][TN], const char* ld
     mma_pass<true, TM, TN>(acc, lds_b, RS, ktaps, dil, nkc, wlane, mtile_stride);
 }
 
+// Pin the point where outstanding loads of `v` are waited for: the compiler's s_waitcnt for a value lands at
+// its first use, and a first use AFTER a conditional block of younger loads degrades to vmcnt(0) -- i.e. it
+// would wait for the prefetched window too.
+template <int N>
+__device__ __forceinline__ void settle(const f32x4 (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" ::"v"(v[i]));
+}
+
 // leaky_relu on 4 values as max(x, slope*x) (0 < slope <= 1): two packed multiplies + four v_max
 __device__ __forceinline__ f32x4 lrelu4(const f32x4& v, float slope) {
     const f32x4 s = v * slope;
@@ -136,12 +145,6 @@ __device__ __forceinline__ f32x4 unpack4_f16(unsigned long long q) {
     return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
 }
 
-// Coalesced window load (float16 activations): rows [t0, t0+W) x C channels of one sequence, 16 bytes per
-// lane along the channel axis.  issue_window16 puts every load of the thread in flight (into registers);
-// commit_window16 writes each unit twice: raw float16 into the Y tile (from where every wave afterwards picks
-// the fragments of its fp32 residual registers) and bf16(lrelu(x)) into the A tile (conv1's B operand).
-// Rows outside [0, len) are zeros in both.  The two halves are separate so that a persistent block can have
-// the NEXT window's rows in flight while it still computes the current one.
 // threadIdx.x behind an opaque move: index arithmetic derived from it is recomputed where it is used
 // instead of being hoisted out of the persistent window loop (where it would sit in ~40 VGPRs through
 // every K loop)
@@ -151,6 +154,13 @@ __device__ __forceinline__ int tid_here() {
     return t;
 }
 
+// Coalesced window load (float16 activations): rows [t0, t0+W) x C channels of one sequence, 16 bytes per
+// lane along the channel axis.  issue_window16 puts every load of the thread in flight (into registers) and
+// commit_raw16 drops them into an LDS tile as raw float16, zeros for rows outside [0, len).  The two halves are
+// separate so that a persistent block can have the NEXT window's rows in flight while it still computes the
+// current one.  The loads are unconditional (row index clamped into the sequence, zeroing deferred to the
+// commit): predicated loads put a phi on every register and the compiler then waits for all of them (vmcnt(0))
+// in the middle of the epilogue that is supposed to hide their latency.
 template <int C, int W, int NTHREADS>
 struct WinLoad {
     static constexpr int UPR = C / 8;
@@ -161,57 +171,37 @@ struct WinLoad {
 template <int C, int W, int NTHREADS>
 __device__ __forceinline__ void issue_window16(const _Float16* xb, int t0, int len,
                                                u32x4 (&raw)[WinLoad<C, W, NTHREADS>::PER]) {
-    const int tid = tid_here();
     using WL = WinLoad<C, W, NTHREADS>;
+    const int tid = tid_here();
+#pragma unroll
+    for (int k = 0; k < WL::PER; ++k) {
+        int idx = tid + k * NTHREADS;
+        if (WL::TOTAL % NTHREADS != 0) idx = idx < WL::TOTAL ? idx : WL::TOTAL - 1;
+        const int r = idx / WL::UPR, u = idx - r * WL::UPR;
+        int g = t0 + r;
+        g = g < 0 ? 0 : g;
+        g = g < len ? g : len - 1;  // len >= 1: only windows of non-empty sequences exist
+        raw[k] = *(const u32x4*)(xb + (long long)g * C + u * 8);
+    }
+}
+
+// the window in flight -> tile T0 as raw float16 (converted in place afterwards, fragment by fragment)
+template <int C, int W, int NTHREADS>
+__device__ __forceinline__ void commit_raw16(const u32x4 (&raw)[WinLoad<C, W, NTHREADS>::PER], char* T0, int RS,
+                                             int t0, int len) {
+    using WL = WinLoad<C, W, NTHREADS>;
+    const int tid = tid_here();
 #pragma unroll
     for (int k = 0; k < WL::PER; ++k) {
         const int idx = tid + k * NTHREADS;
+        if (WL::TOTAL % NTHREADS != 0 && idx >= WL::TOTAL) continue;
         const int r = idx / WL::UPR, u = idx - r * WL::UPR;
         const int g = t0 + r;
-        raw[k] = u32x4{0u, 0u, 0u, 0u};
-        if (idx < WL::TOTAL && g >= 0 && g < len) raw[k] = *(const u32x4*)(xb + (long long)g * C + u * 8);
+        const bool ok = g >= 0 && g < len;
+        u32x4 v = raw[k];
+        if (!ok) v = u32x4{0u, 0u, 0u, 0u};
+        *(u32x4*)(T0 + r * RS + u * 16) = v;
     }
-}
-
-template <int C, int W, int NTHREADS>
-__device__ __forceinline__ void commit_window16(const u32x4 (&raw)[WinLoad<C, W, NTHREADS>::PER], char* A0, char* Y0,
-                                                int RS) {
-    const int tid = tid_here();
-    using WL = WinLoad<C, W, NTHREADS>;
-#pragma unroll
-    for (int k = 0; k < WL::PER; ++k) {
-        const int idx = tid + k * NTHREADS;
-        if (idx >= WL::TOTAL) continue;
-        const int r = idx / WL::UPR, u = idx - r * WL::UPR;
-        const f16x8 h = __builtin_bit_cast(f16x8, raw[k]);
-        const f32x4 lo = lrelu4(f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]}, 0.1f);
-        const f32x4 hi = lrelu4(f32x4{(float)h[4], (float)h[5], (float)h[6], (float)h[7]}, 0.1f);
-        const u32x4 v = {pack_bf16(lo[0], lo[1]), pack_bf16(lo[2], lo[3]), pack_bf16(hi[0], hi[1]),
-                         pack_bf16(hi[2], hi[3])};
-        *(u32x4*)(Y0 + r * RS + u * 16) = raw[k];
-        *(u32x4*)(A0 + r * RS + u * 16) = v;
-    }
-}
-
-// the window in flight -> tile T0 as raw float16 (fused_rb_kernel converts it in place, fragment by fragment)
-template <int C, int W, int NTHREADS>
-__device__ __forceinline__ void commit_raw16(const u32x4 (&raw)[WinLoad<C, W, NTHREADS>::PER], char* T0, int RS) {
-    const int tid = tid_here();
-    using WL = WinLoad<C, W, NTHREADS>;
-#pragma unroll
-    for (int k = 0; k < WL::PER; ++k) {
-        const int idx = tid + k * NTHREADS;
-        if (idx >= WL::TOTAL) continue;
-        const int r = idx / WL::UPR, u = idx - r * WL::UPR;
-        *(u32x4*)(T0 + r * RS + u * 16) = raw[k];
-    }
-}
-
-template <int C, int W, int NTHREADS>
-__device__ __forceinline__ void load_window16(const _Float16* xb, int t0, int len, char* A0, char* Y0, int RS) {
-    u32x4 raw[WinLoad<C, W, NTHREADS>::PER];
-    issue_window16<C, W, NTHREADS>(xb, t0, len, raw);
-    commit_window16<C, W, NTHREADS>(raw, A0, Y0, RS);
 }
 
 // Persistent blocks walk the list of (sequence, window) pairs that actually exist: cum[b] = number of
@@ -358,7 +348,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
         if (io16x) {  // the block's first window arrives synchronously, every later one is prefetched
             u32x4 raw[WL::PER];
             issue_window16<C, W, NTHREADS>((const _Float16*)p.x + (long long)b * p.batch_stride, t0, len, raw);
-            commit_raw16<C, W, NTHREADS>(raw, A0, RS);
+            commit_raw16<C, W, NTHREADS>(raw, A0, RS, t0, len);
             __syncthreads();
         }
     }
@@ -444,6 +434,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
             conv_window<TM, TN>(acc, A0 + ((wn * TN * 16 + lr) - pad1) * RS + lg * 16, RS, p.K, d, NKC,
                                 (const u32x4*)p.w1[m] + woff, mtile_stride);
             MV_LAP(tr, TR_KLOOP);
+            settle(bias);
             // Prefetch: conv1 of the last pair is done with the A tile after the next barrier and nothing reads
             // it again until the next window, so the next window's rows are requested here (their HBM latency
             // hides under this epilogue and the barrier) and dropped into the A tile before conv2 starts.
@@ -476,7 +467,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
             __syncthreads();  // Y16 complete, A16 free
             MV_LAP(tr, TR_BARRIER);
             if constexpr (XREG) {
-                if (pf) commit_raw16<C, W, NTHREADS>(raw, A0, RS);
+                if (pf) commit_raw16<C, W, NTHREADS>(raw, A0, RS, t0n, lenn);
             }
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) bias[tm] = *(const f32x4*)(p.b2[m] + chq + tm * 16);
@@ -649,7 +640,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
     if (p.io16) {  // the block's first window arrives synchronously, every later one is prefetched
         u32x4 raw[WL::PER];
         issue_window16<C, W, NTHREADS>((const _Float16*)p.x + (long long)b * p.batch_stride, out0 - p.H, len, raw);
-        commit_raw16<C, W, NTHREADS>(raw, A0, RS);
+        commit_raw16<C, W, NTHREADS>(raw, A0, RS, out0 - p.H, len);
         __syncthreads();
     }
     MV_LAP(tr, TR_SETUP);
@@ -726,6 +717,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
                 conv_window<TM, TN>(acc, A0 + ((wn * TN * 16 + lr) - pad1) * RS + lg * 16, RS, K, d, NKC,
                                     (const u32x4*)p.w1[j][m] + woff, mtile_stride);
                 MV_LAP(tr, TR_KLOOP);
+                settle(bias);
                 // Under the last conv1 epilogue of a ResBlock: request the rows the next ResBlock starts from -- the
                 // same window again (L2-hot), or the next window after the last ResBlock (see fused_rb_kernel).
                 const bool last_rb = j == p.nrb - 1;
@@ -759,7 +751,12 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
                 MV_LAP(tr, TR_EPI);
                 __syncthreads();
                 MV_LAP(tr, TR_BARRIER);
-                if (pf) commit_raw16<C, W, NTHREADS>(raw, A0, RS);
+                if (pf) {
+                    if (last_rb)
+                        commit_raw16<C, W, NTHREADS>(raw, A0, RS, out0n - p.H, lenn);
+                    else
+                        commit_raw16<C, W, NTHREADS>(raw, A0, RS, t0, len);
+                }
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm) bias[tm] = *(const f32x4*)(p.b2[j][m] + chq + tm * 16);
                 conv_window<TM, TN>(acc, Y0 + ((wn * TN * 16 + lr) - pad2) * RS + lg * 16, RS, K, 1, NKC,
