@@ -270,55 +270,88 @@ __device__ __forceinline__ void mma_step(f32x4 (&acc)[TM][TN], const u32x4 (&a)[
     }
 }
 
+// The weight stream of one wave: a scalar buffer descriptor over the wave's first M tile + a 32-bit lane offset.
+// The wave-uniform part of the address (every lane of a wave reads the same M tiles) sits in SGPRs, so stepping
+// through K costs scalar adds only (global_load took two 64-bit VALU adds per fragment, between the MFMAs).
+template <int TM>
+struct WStream {
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned lane_off;
+    int mtile_bytes;
+    int S;  // K steps of the pass (fragments per M tile)
+
+    __device__ __forceinline__ WStream(const u32x4* wlane, long long mtile_stride, int steps) {
+        lane_off = (threadIdx.x & 63u) * 16u;
+        const unsigned long long wu = (unsigned long long)(wlane - (threadIdx.x & 63u));
+        // (readfirstlane returns int: go through unsigned, or the low half sign-extends into the high half)
+        const unsigned w_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(wu >> 32));
+        const unsigned w_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wu);
+        void* wbase = (void*)(((unsigned long long)w_hi << 32) | (unsigned long long)w_lo);
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(wbase, 0, 0x7fffffff, 0x00020000);
+        mtile_bytes = (int)(mtile_stride * 16);
+        S = steps;
+    }
+    // fragments of K step `step` (clamped to the last one: prefetches past the end re-read it, harmlessly)
+    __device__ __forceinline__ void fetch(u32x4 (&a)[TM + MV_XA], int step) const {
+        const int sn = step < S ? step : S - 1;
+#if MV_XA
+        a[TM] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, sn * 1024, 0);
+#endif
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+#if defined(MV_ABLATE) && (MV_ABLATE & 4)
+            a[tm] = u32x4{(unsigned)sn, 0u, 0u, 0u};  // timing-only build: no weight loads
+#else
+            a[tm] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, tm * mtile_bytes + sn * 1024, 0);
+#endif
+        }
+    }
+};
+
+// The first four K steps' fragments of a pass, requested ahead of it (fused kernels: under the previous conv's
+// epilogue and barrier, so a conv does not start by waiting an L2 round trip for its first weights).
+template <int TM>
+struct APre {
+    u32x4 a[4][TM + MV_XA];
+    __device__ __forceinline__ void request(const u32x4* wlane, long long mtile_stride, int steps) {
+        const WStream<TM> ws(wlane, mtile_stride, steps);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ws.fetch(a[i], i);
+    }
+};
+
 // One pass of the K loop: S = ktaps * nkc steps.  A fragments stream L2 -> registers FOUR steps
 // ahead (a wave keeps 4*TM KiB in flight: with two steps the weight stream, not the matrix pipe,
 // paced the loop), B fragments come from LDS one group ahead.  The loop body is branch-free
 // (prefetch indices are clamped, not guarded) so the accumulators stay in place.
 template <bool BF16, int TM, int TN>
 __device__ __forceinline__ void mma_pass(f32x4 (&acc)[TM][TN], const char* lds_b, int RS, int ktaps, int dil, int nkc,
-                                         const u32x4* wlane, long long mtile_stride) {
+                                         const u32x4* wlane, long long mtile_stride, const APre<TM>* pre = nullptr) {
     constexpr int G = BPipe<TM, TN>::G, NG = BPipe<TM, TN>::NG;
     constexpr int P1 = NG & 1;  // buffer parity of the 2nd / 4th step of an unrolled group
     const int S = ktaps * nkc;
     const int tap_wrap = dil * RS - nkc * 64;
     u32x4 a0[TM + MV_XA], a1[TM + MV_XA], a2[TM + MV_XA], a3[TM + MV_XA];
     u32x4 q0[G], q1[G];
-    // Weight fragments come through buffer loads: the wave-uniform part of the address (every lane of a wave
-    // reads the same M tiles) sits in a scalar buffer descriptor + scalar offset, the lane part is one 32-bit
-    // VGPR, so stepping through K costs scalar adds only (global_load took two 64-bit VALU adds per fragment,
-    // issued between the MFMAs).
-    const unsigned lane_off = (threadIdx.x & 63u) * 16u;
-    const unsigned long long wu = (unsigned long long)(wlane - (threadIdx.x & 63u));
-    // (readfirstlane returns int: go through unsigned, or the low half sign-extends into the high half)
-    const unsigned w_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(wu >> 32));
-    const unsigned w_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wu);
-    void* wbase = (void*)(((unsigned long long)w_hi << 32) | (unsigned long long)w_lo);
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(wbase, 0, 0x7fffffff, 0x00020000);
-    const int mtile_bytes = (int)(mtile_stride * 16);
-    auto fetch = [&](u32x4 (&a)[TM + MV_XA], int step) {
-        const int sn = step < S ? step : S - 1;
-#if MV_XA
-        a[TM] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_off, sn * 1024, 0);
-#endif
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-#if defined(MV_ABLATE) && (MV_ABLATE & 4)
-            a[tm] = u32x4{(unsigned)sn, 0u, 0u, 0u};  // timing-only build: no weight loads
-#elif defined(MV_ABLATE) && (MV_ABLATE & 32)
-            // timing-only build: weight fragments read from LDS (garbage) instead of L2
-            a[tm] = *(const u32x4*)(lds_b + ((sn & 3) * 4 + tm) * 1024 + (threadIdx.x & 63) * 16 - (size_t)0);
-#else
-            a[tm] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_off, tm * mtile_bytes + sn * 1024, 0);
-#endif
-        }
-    };
+    const WStream<TM> ws(wlane, mtile_stride, S);
+    auto fetch = [&](u32x4 (&a)[TM + MV_XA], int step) { ws.fetch(a, step); };
 #if defined(MV_ABLATE) && (MV_ABLATE & 8)
     return;  // timing-only build: no K loop at all (staging, epilogues and barriers remain)
 #endif
-    fetch(a0, 0);
-    fetch(a1, 1);
-    fetch(a2, 2);
-    fetch(a3, 3);
+    if (pre) {
+#pragma unroll
+        for (int t = 0; t < TM + MV_XA; ++t) {
+            a0[t] = pre->a[0][t];
+            a1[t] = pre->a[1][t];
+            a2[t] = pre->a[2][t];
+            a3[t] = pre->a[3][t];
+        }
+    } else {
+        fetch(a0, 0);
+        fetch(a1, 1);
+        fetch(a2, 2);
+        fetch(a3, 3);
+    }
     int kc = 0;
     const char* bp = lds_b;  // advances 64 B per k-chunk, wraps to the next tap
     load_bgroup<TN, G>(q0, bp, RS, 0);

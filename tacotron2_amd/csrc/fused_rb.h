@@ -102,12 +102,13 @@ struct FusedRbParams {
 
 template <int TM, int TN>
 __device__ __forceinline__ void conv_window(f32x4 (&acc)[TM][TN], const char* lds_b, int RS, int ktaps, int dil,
-                                            int nkc, const u32x4* wlane, long long mtile_stride) {
+                                            int nkc, const u32x4* wlane, long long mtile_stride,
+                                            const APre<TM>* pre = nullptr) {
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
-    mma_pass<true, TM, TN>(acc, lds_b, RS, ktaps, dil, nkc, wlane, mtile_stride);
+    mma_pass<true, TM, TN>(acc, lds_b, RS, ktaps, dil, nkc, wlane, mtile_stride, pre);
 }
 
 // Pin the point where outstanding loads of `v` are waited for: the compiler's s_waitcnt for a value lands at
@@ -356,6 +357,10 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
 
     f32x4 X[XREG ? TM : 1][XREG ? TN : 1];
     f32x4 acc[TM][TN];
+    // the first weight fragments of every conv are requested while the conv before it winds down (epilogue,
+    // barrier, window hand-over), so no K loop starts by waiting an L2 round trip
+    APre<TM> wpre;
+    wpre.request((const u32x4*)p.w1[0] + woff, mtile_stride, p.K * NKC);
     for (;;) {
         const bool interior = t0 >= 0 && t0 + W <= len;  // no row of the window needs masking
         const void* xb = p.io16 ? (const void*)((const _Float16*)p.x + (long long)b * p.batch_stride)
@@ -432,9 +437,10 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) bias[tm] = *(const f32x4*)(p.b1[m] + chq + tm * 16);
             conv_window<TM, TN>(acc, A0 + ((wn * TN * 16 + lr) - pad1) * RS + lg * 16, RS, p.K, d, NKC,
-                                (const u32x4*)p.w1[m] + woff, mtile_stride);
+                                (const u32x4*)p.w1[m] + woff, mtile_stride, &wpre);
             MV_LAP(tr, TR_KLOOP);
             settle(bias);
+            wpre.request((const u32x4*)p.w2[m] + woff, mtile_stride, p.K * NKC);
             // Prefetch: conv1 of the last pair is done with the A tile after the next barrier and nothing reads
             // it again until the next window, so the next window's rows are requested here (their HBM latency
             // hides under this epilogue and the barrier) and dropped into the A tile before conv2 starts.
@@ -472,8 +478,10 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) bias[tm] = *(const f32x4*)(p.b2[m] + chq + tm * 16);
             conv_window<TM, TN>(acc, Y0 + ((wn * TN * 16 + lr) - pad2) * RS + lg * 16, RS, p.K, 1, NKC,
-                                (const u32x4*)p.w2[m] + woff, mtile_stride);
+                                (const u32x4*)p.w2[m] + woff, mtile_stride, &wpre);
             MV_LAP(tr, TR_KLOOP);
+            settle(bias);
+            wpre.request((const u32x4*)p.w1[m + 1 < p.npair ? m + 1 : 0] + woff, mtile_stride, p.K * NKC);
             if constexpr (XREG) {
                 const bool more = m + 1 < p.npair;
 #pragma unroll
@@ -646,6 +654,9 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
     MV_LAP(tr, TR_SETUP);
 
     f32x4 X[TM][TN], SUM[TM][TN], acc[TM][TN];
+    APre<TM> wpre;  // see fused_rb_kernel
+    wpre.request((const u32x4*)p.w1[0][0] + (long long)(wm * TM) * ((long long)p.K[0] * NKC * 64) + lane,
+                 (long long)p.K[0] * NKC * 64, p.K[0] * NKC);
     for (;;) {
         const int t0 = out0 - p.H;
         const bool interior = t0 >= 0 && t0 + W <= len;
@@ -715,9 +726,10 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm) bias[tm] = *(const f32x4*)(p.b1[j][m] + chq + tm * 16);
                 conv_window<TM, TN>(acc, A0 + ((wn * TN * 16 + lr) - pad1) * RS + lg * 16, RS, K, d, NKC,
-                                    (const u32x4*)p.w1[j][m] + woff, mtile_stride);
+                                    (const u32x4*)p.w1[j][m] + woff, mtile_stride, &wpre);
                 MV_LAP(tr, TR_KLOOP);
                 settle(bias);
+                wpre.request((const u32x4*)p.w2[j][m] + woff, mtile_stride, K * NKC);
                 // Under the last conv1 epilogue of a ResBlock: request the rows the next ResBlock starts from -- the
                 // same window again (L2-hot), or the next window after the last ResBlock (see fused_rb_kernel).
                 const bool last_rb = j == p.nrb - 1;
@@ -760,8 +772,16 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm) bias[tm] = *(const f32x4*)(p.b2[j][m] + chq + tm * 16);
                 conv_window<TM, TN>(acc, Y0 + ((wn * TN * 16 + lr) - pad2) * RS + lg * 16, RS, K, 1, NKC,
-                                    (const u32x4*)p.w2[j][m] + woff, mtile_stride);
+                                    (const u32x4*)p.w2[j][m] + woff, mtile_stride, &wpre);
                 MV_LAP(tr, TR_KLOOP);
+                settle(bias);
+                {
+                    // next conv: the next pair of this ResBlock, or the next ResBlock's (the next window's) first
+                    const int jn = m < 2 ? j : (j + 1 < p.nrb ? j + 1 : 0);
+                    const int mn = m < 2 ? m + 1 : 0;
+                    const long long msn = (long long)p.K[jn] * NKC * 64;
+                    wpre.request((const u32x4*)p.w1[jn][mn] + (long long)(wm * TM) * msn + lane, msn, p.K[jn] * NKC);
+                }
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) {
                     const int g = t0 + (wn * TN + tn) * 16 + lr;
