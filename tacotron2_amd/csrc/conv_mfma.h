@@ -310,28 +310,31 @@ struct WStream {
 
 // The first four K steps' fragments of a pass, requested ahead of it (fused kernels: under the previous conv's
 // epilogue and barrier, so a conv does not start by waiting an L2 round trip for its first weights).
-template <int TM>
+template <int TM, int DEPTH = 4>
 struct APre {
-    u32x4 a[4][TM + MV_XA];
+    u32x4 a[DEPTH][TM + MV_XA];
     __device__ __forceinline__ void request(const u32x4* wlane, long long mtile_stride, int steps) {
         const WStream<TM> ws(wlane, mtile_stride, steps);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ws.fetch(a[i], i);
+        for (int i = 0; i < DEPTH; ++i) ws.fetch(a[i], i);
     }
 };
 
 // One pass of the K loop: S = ktaps * nkc steps.  A fragments stream L2 -> registers FOUR steps
 // ahead (a wave keeps 4*TM KiB in flight: with two steps the weight stream, not the matrix pipe,
 // paced the loop), B fragments come from LDS one group ahead.  The loop body is branch-free
-// (prefetch indices are clamped, not guarded) so the accumulators stay in place.
-template <bool BF16, int TM, int TN>
+// (prefetch indices are clamped, not guarded) so the accumulators stay in place.  DEPTH = 2 keeps two steps
+// in flight instead of four (16 VGPRs less; for the register-bound stage kernels with their short K loops).
+template <bool BF16, int TM, int TN, int DEPTH = 4>
 __device__ __forceinline__ void mma_pass(f32x4 (&acc)[TM][TN], const char* lds_b, int RS, int ktaps, int dil, int nkc,
-                                         const u32x4* wlane, long long mtile_stride, const APre<TM>* pre = nullptr) {
+                                         const u32x4* wlane, long long mtile_stride,
+                                         const APre<TM, DEPTH>* pre = nullptr) {
+    static_assert(DEPTH == 2 || DEPTH == 4, "two or four K steps of weights in flight");
     constexpr int G = BPipe<TM, TN>::G, NG = BPipe<TM, TN>::NG;
     constexpr int P1 = NG & 1;  // buffer parity of the 2nd / 4th step of an unrolled group
     const int S = ktaps * nkc;
     const int tap_wrap = dil * RS - nkc * 64;
-    u32x4 a0[TM + MV_XA], a1[TM + MV_XA], a2[TM + MV_XA], a3[TM + MV_XA];
+    u32x4 a0[TM + MV_XA], a1[TM + MV_XA], a2[DEPTH == 4 ? TM + MV_XA : 1], a3[DEPTH == 4 ? TM + MV_XA : 1];
     u32x4 q0[G], q1[G];
     const WStream<TM> ws(wlane, mtile_stride, S);
     auto fetch = [&](u32x4 (&a)[TM + MV_XA], int step) { ws.fetch(a, step); };
@@ -343,14 +346,18 @@ __device__ __forceinline__ void mma_pass(f32x4 (&acc)[TM][TN], const char* lds_b
         for (int t = 0; t < TM + MV_XA; ++t) {
             a0[t] = pre->a[0][t];
             a1[t] = pre->a[1][t];
-            a2[t] = pre->a[2][t];
-            a3[t] = pre->a[3][t];
+            if constexpr (DEPTH == 4) {
+                a2[t] = pre->a[2][t];
+                a3[t] = pre->a[3][t];
+            }
         }
     } else {
         fetch(a0, 0);
         fetch(a1, 1);
-        fetch(a2, 2);
-        fetch(a3, 3);
+        if constexpr (DEPTH == 4) {
+            fetch(a2, 2);
+            fetch(a3, 3);
+        }
     }
     int kc = 0;
     const char* bp = lds_b;  // advances 64 B per k-chunk, wraps to the next tap
@@ -364,6 +371,18 @@ __device__ __forceinline__ void mma_pass(f32x4 (&acc)[TM][TN], const char* lds_b
         return n;
     };
     int s = 0;
+    if constexpr (DEPTH == 2) {
+        for (; s + 2 <= S; s += 2) {
+            const char* bp1 = next_bp(bp);
+            mma_step<BF16, TM, TN, 0>(acc, a0, bp, bp1, RS, q0, q1);
+            fetch(a0, s + 2);
+            const char* bp2 = s + 2 < S ? next_bp(bp1) : bp1;
+            mma_step<BF16, TM, TN, P1>(acc, a1, bp1, bp2, RS, q0, q1);
+            fetch(a1, s + 3);
+            bp = bp2;
+        }
+        if (s < S) mma_step<BF16, TM, TN, 0>(acc, a0, bp, bp, RS, q0, q1);
+    } else {
     for (; s + 4 <= S; s += 4) {
         const char* bp1 = next_bp(bp);
         mma_step<BF16, TM, TN, 0>(acc, a0, bp, bp1, RS, q0, q1);
@@ -388,6 +407,7 @@ __device__ __forceinline__ void mma_pass(f32x4 (&acc)[TM][TN], const char* lds_b
             mma_step<BF16, TM, TN, P1>(acc, a1, bp1, bp2, RS, q0, q1);
             if (s + 2 < S) mma_step<BF16, TM, TN, 0>(acc, a2, bp2, bp2, RS, q0, q1);
         }
+    }
     }
 }
 

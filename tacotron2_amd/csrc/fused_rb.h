@@ -100,15 +100,15 @@ struct FusedRbParams {
     int guardY;   // (K-1)/2
 };
 
-template <int TM, int TN>
+template <int TM, int TN, int DEPTH = 4>
 __device__ __forceinline__ void conv_window(f32x4 (&acc)[TM][TN], const char* lds_b, int RS, int ktaps, int dil,
                                             int nkc, const u32x4* wlane, long long mtile_stride,
-                                            const APre<TM>* pre = nullptr) {
+                                            const APre<TM, DEPTH>* pre = nullptr) {
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
-    mma_pass<true, TM, TN>(acc, lds_b, RS, ktaps, dil, nkc, wlane, mtile_stride, pre);
+    mma_pass<true, TM, TN, DEPTH>(acc, lds_b, RS, ktaps, dil, nkc, wlane, mtile_stride, pre);
 }
 
 // Pin the point where outstanding loads of `v` are waited for: the compiler's s_waitcnt for a value lands at
@@ -569,6 +569,10 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
 // written.  Same window scheme as fused_rb_kernel; every ResBlock restarts from the stage input x
 // (re-read from L2 into registers) and the running sum of their outputs stays in registers.
 // The window halo is that of the widest ResBlock (k = 11: 60 rows a side).
+#ifndef MV_STAGE_ADEPTH
+#define MV_STAGE_ADEPTH 2  // K steps of weights in flight in the stage kernels (register-bound)
+#endif
+
 struct FusedStageParams {
     const void* x;   // [B][rows][C] float32, or float16 when io16
     void* out;       // [B][rows][C] mean of the ResBlocks, same type (unused when post_w is set)
@@ -597,7 +601,9 @@ struct FusedStageParams {
     int wav_pcm16;
 };
 
-template <int C, int WM, int WN, int TN>
+// IO16 (p.io16) and POST (p.post_w != null) are compile-time: with the four variants in one function the
+// register allocator budgets for the union of their live ranges and spills ~50 VGPRs in the one that runs.
+template <int C, int WM, int WN, int TN, bool IO16, bool POST>
 __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedStageParams p) {
     constexpr int TM = C / 16 / WM;
     constexpr int W = 16 * TN * WN;
@@ -645,7 +651,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
     int b = find_seq(cum_s, p.B, v);
     int len = (p.lengths ? p.lengths[b] : p.Tmax) * p.rows_per_frame;
     int out0 = (v - cum_s[b]) * p.NT;
-    if (p.io16) {  // the block's first window arrives synchronously, every later one is prefetched
+    if constexpr (IO16) {  // the block's first window arrives synchronously, every later one is prefetched
         u32x4 raw[WL::PER];
         issue_window16<C, W, NTHREADS>((const _Float16*)p.x + (long long)b * p.batch_stride, out0 - p.H, len, raw);
         commit_raw16<C, W, NTHREADS>(raw, A0, RS, out0 - p.H, len);
@@ -653,14 +659,19 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
     }
     MV_LAP(tr, TR_SETUP);
 
-    f32x4 X[TM][TN], SUM[TM][TN], acc[TM][TN];
-    APre<TM> wpre;  // see fused_rb_kernel
+    // The running sum of the ResBlocks' outputs is parked as packed float16 between ResBlocks (24 registers
+    // instead of 48: with fp32 the compiler spilled half of it to scratch, ~1 GB of HBM traffic per launch);
+    // it is added to in fp32 and rounded once per ResBlock (2^-11 relative, the storage format of the result).
+    f32x4 X[TM][TN], acc[TM][TN];
+    unsigned long long SUM16[TM][TN];
+    constexpr int ADEPTH = MV_STAGE_ADEPTH;
+    APre<TM, ADEPTH> wpre;  // see fused_rb_kernel
     wpre.request((const u32x4*)p.w1[0][0] + (long long)(wm * TM) * ((long long)p.K[0] * NKC * 64) + lane,
                  (long long)p.K[0] * NKC * 64, p.K[0] * NKC);
     for (;;) {
         const int t0 = out0 - p.H;
         const bool interior = t0 >= 0 && t0 + W <= len;
-        const void* xb = p.io16 ? (const void*)((const _Float16*)p.x + (long long)b * p.batch_stride)
+        const void* xb = IO16 ? (const void*)((const _Float16*)p.x + (long long)b * p.batch_stride)
                                 : (const void*)((const float*)p.x + (long long)b * p.batch_stride);
         const int vn = v + (int)gridDim.x;
         const bool has_next = vn < V;
@@ -675,7 +686,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
             const long long mtile_stride = (long long)K * NKC * 64;
             const long long woff = (long long)(wm * TM) * mtile_stride + lane;
             const int pad2 = (K - 1) / 2;
-            if (p.io16) {
+            if constexpr (IO16) {
                 // (every ResBlock restarts from the stage input: its rows were re-requested under the previous
                 // ResBlock's last conv1 epilogue and sit in the A tile as raw float16, like a new window's)
                 // raw float16 window in the A tile -> fp32 residual registers + bf16(lrelu) in place
@@ -725,7 +736,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
                 f32x4 bias[TM];
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm) bias[tm] = *(const f32x4*)(p.b1[j][m] + chq + tm * 16);
-                conv_window<TM, TN>(acc, A0 + ((wn * TN * 16 + lr) - pad1) * RS + lg * 16, RS, K, d, NKC,
+                conv_window<TM, TN, ADEPTH>(acc, A0 + ((wn * TN * 16 + lr) - pad1) * RS + lg * 16, RS, K, d, NKC,
                                     (const u32x4*)p.w1[j][m] + woff, mtile_stride, &wpre);
                 MV_LAP(tr, TR_KLOOP);
                 settle(bias);
@@ -733,7 +744,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
                 // Under the last conv1 epilogue of a ResBlock: request the rows the next ResBlock starts from -- the
                 // same window again (L2-hot), or the next window after the last ResBlock (see fused_rb_kernel).
                 const bool last_rb = j == p.nrb - 1;
-                const bool pf = p.io16 && m == 2 && (!last_rb || has_next);
+                const bool pf = IO16 && m == 2 && (!last_rb || has_next);
                 u32x4 raw[WL::PER];
                 if (pf) {
                     if (last_rb)
@@ -771,7 +782,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
                 }
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm) bias[tm] = *(const f32x4*)(p.b2[j][m] + chq + tm * 16);
-                conv_window<TM, TN>(acc, Y0 + ((wn * TN * 16 + lr) - pad2) * RS + lg * 16, RS, K, 1, NKC,
+                conv_window<TM, TN, ADEPTH>(acc, Y0 + ((wn * TN * 16 + lr) - pad2) * RS + lg * 16, RS, K, 1, NKC,
                                     (const u32x4*)p.w2[j][m] + woff, mtile_stride, &wpre);
                 MV_LAP(tr, TR_KLOOP);
                 settle(bias);
@@ -795,24 +806,31 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
                     }
                 }
             }
+            if (j + 1 < p.nrb) {
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
+                for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn) SUM[tm][tn] = j == 0 ? X[tm][tn] : SUM[tm][tn] + X[tm][tn];
+                    for (int tn = 0; tn < TN; ++tn)
+                        SUM16[tm][tn] = pack4_f16_sat(j == 0 ? X[tm][tn] : unpack4_f16(SUM16[tm][tn]) + X[tm][tn]);
+            }
         }
+        // mean over the ResBlocks (models.py:160); the last ResBlock's output is still in fp32 registers
+        f32x4 SUM[TM][TN];
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
+            for (int tn = 0; tn < TN; ++tn) {
+                SUM[tm][tn] = p.nrb > 1 ? unpack4_f16(SUM16[tm][tn]) + X[tm][tn] : X[tm][tn];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) SUM[tm][tn][i] = SUM[tm][tn][i] / p.div;
+            }
 
         MV_LAP(tr, TR_EPI);
         // The result leaves through the Y tile (the A tile may already hold the next window).
         __syncthreads();  // every wave is done reading Y16 as the last conv2's operand
         MV_LAP(tr, TR_BARRIER);
-        if (!p.post_w) {
-            if (p.io16) {
+        if constexpr (!POST) {
+            if constexpr (IO16) {
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
@@ -915,7 +933,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
         // io16: the barrier after the next window's in-place conversion separates these reads of the Y tile
         // from the next conv1 epilogue that overwrites it; the fp32 path syncs at the top of the loop
     }
-    MV_FLUSH(tr, (C << 16) | (p.post_w ? 0xfe00 : 0xff00) | p.nrb);
+    MV_FLUSH(tr, (C << 16) | (POST ? 0xfe00 : 0xff00) | p.nrb);
 }
 
 }  // namespace mv

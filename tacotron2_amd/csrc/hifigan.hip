@@ -76,12 +76,17 @@ static bool fuse_whole(const FusedCfg& fc, int K, const int* dils) {
 typedef void (*StageKernel)(const FusedStageParams);
 struct StageCfg {
     int C, W, threads;
-    StageKernel k;
+    StageKernel k[2][2];  // [io16][with conv_post]
     const char* name;
 };
 static const StageCfg kStage[] = {
-    {32, 768, 512, fused_stage_kernel<32, 1, 8, 6>, "fused_stage_kernel<C32,WM1,WN8,TN6>"},
-    {64, 384, 512, fused_stage_kernel<64, 2, 4, 6>, "fused_stage_kernel<C64,WM2,WN4,TN6>"},
+#define MV_STAGE_VARIANTS(C, WM, WN, TN)                                                               \
+    {                                                                                                  \
+        {fused_stage_kernel<C, WM, WN, TN, false, false>, fused_stage_kernel<C, WM, WN, TN, false, true>}, \
+        {fused_stage_kernel<C, WM, WN, TN, true, false>, fused_stage_kernel<C, WM, WN, TN, true, true>},   \
+    }
+    {32, 768, 512, MV_STAGE_VARIANTS(32, 1, 8, 6), "fused_stage_kernel<C32,WM1,WN8,TN6>"},
+    {64, 384, 512, MV_STAGE_VARIANTS(64, 2, 4, 6), "fused_stage_kernel<C64,WM2,WN4,TN6>"},
 };
 static const StageCfg* stage_cfg_for(int Cp) {
     static const int mode = env_or("MV_STAGE", 3);  // bit 0: C32, bit 1: C64
@@ -94,7 +99,10 @@ int init_fused_attributes() {
     for (const FusedCfg& f : kFused)
         MV_HIP(hipFuncSetAttribute((const void*)f.k, hipFuncAttributeMaxDynamicSharedMemorySize, kFusedMaxLds));
     for (const StageCfg& f : kStage)
-        MV_HIP(hipFuncSetAttribute((const void*)f.k, hipFuncAttributeMaxDynamicSharedMemorySize, kFusedMaxLds));
+        for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 2; ++b)
+                MV_HIP(hipFuncSetAttribute((const void*)f.k[a][b], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           kFusedMaxLds));
     return MV_OK;
 }
 
@@ -484,7 +492,7 @@ static int launch_fused_stage(const StageCfg& sc, const HifiganHandle* h, int i,
     // the persistent blocks visit only windows that exist; the waveform past a sequence's end is zero
     if (wav) MV_HIP(hipMemsetAsync(wav, 0, (size_t)B * rows * (out_format == MV_OUT_PCM16 ? 2 : 4), stream));
     if (prof) prof->begin(stream, wav ? std::string(sc.name) + "+conv_post" : std::string(sc.name), macs * rpf);
-    hipLaunchKernelGGL(sc.k, grid, dim3(sc.threads), lds, stream, p);
+    hipLaunchKernelGGL(sc.k[io16 ? 1 : 0][wav ? 1 : 0], grid, dim3(sc.threads), lds, stream, p);
     if (prof) prof->end(stream);
     MV_HIP(hipGetLastError());
     return MV_OK;
