@@ -289,7 +289,9 @@ __device__ __forceinline__ void store_window16(_Float16* ob, const char* T0, int
     }
 }
 
-template <int C, int WM, int WN, int TN, bool XREG>
+// IO16X: float16 window IO through LDS with prefetch (XREG kernels, p.io16 set) -- compile-time for the same
+// reason as in fused_stage_kernel (one variant per function keeps the register allocator from spilling).
+template <int C, int WM, int WN, int TN, bool XREG, bool IO16X = false>
 __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbParams p) {
     constexpr int TM = C / 16 / WM;
     constexpr int W = 16 * TN * WN;
@@ -340,13 +342,13 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
     const long long woff = (long long)(wm * TM) * mtile_stride + lane;
     const int pad2 = (p.K - 1) / 2;
     const int chq = (wm * TM) * 16 + lg * 4;  // first channel of this lane's tm = 0 fragment
-    const bool io16x = XREG && p.io16;        // float16 windows come and go through LDS, next one prefetched
+    constexpr bool io16x = XREG && IO16X;     // float16 windows come and go through LDS, next one prefetched
 
     int b = find_seq(cum_s, p.B, v);
     int len = (p.lengths ? p.lengths[b] : p.Tmax) * p.rows_per_frame;
     int t0 = (v - cum_s[b]) * p.NT - p.H;     // global row of window row 0
     if constexpr (XREG) {
-        if (io16x) {  // the block's first window arrives synchronously, every later one is prefetched
+        if constexpr (io16x) {  // the block's first window arrives synchronously, every later one is prefetched
             u32x4 raw[WL::PER];
             issue_window16<C, W, NTHREADS>((const _Float16*)p.x + (long long)b * p.batch_stride, t0, len, raw);
             commit_raw16<C, W, NTHREADS>(raw, A0, RS, t0, len);
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
         void* ob = p.io16 ? (void*)((_Float16*)p.out + (long long)b * p.batch_stride)
                           : (void*)((float*)p.out + (long long)b * p.batch_stride);
         if constexpr (XREG) {
-            if (io16x) {
+            if constexpr (io16x) {
                 // The A tile holds the window as raw float16 (rows outside the sequence are zeros).  Each lane
                 // takes its own fragments as the fp32 residual and leaves bf16(lrelu(x)) in their place.
                 // (all reads first: one LDS round trip for the lot instead of one per fragment)
@@ -501,7 +503,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
 
         MV_LAP(tr, TR_EPI);
         // ---- store the rows the halo has not reached, with the MRF accumulation of models.py:154-160
-        if (io16x) {
+        if constexpr (io16x) {
             // the result leaves as float16 through the Y tile (the A tile may already hold the next window)
             __syncthreads();  // every wave is done reading Y16 as conv2's operand
             MV_LAP(tr, TR_BARRIER);
@@ -554,7 +556,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
         b = bn;
         len = lenn;
         t0 = t0n;
-        if (!io16x) {
+        if constexpr (!io16x) {
             __syncthreads();  // every wave is done with this window's tiles before the next one lands in them
             MV_LAP(tr, TR_BARRIER);
         }

@@ -31,18 +31,23 @@ struct FusedCfg {
     int C, W, threads, npair;
     FusedKernel k;
     const char* name;
+    FusedKernel k16;  // float16-IO variant (XREG kernels), null if there is none
 };
 //                         C   WM WN TN  XREG
 static const FusedCfg kFused[] = {
     // 8 waves (two per SIMD): the second wave hides LDS / L2 latency and the epilogue phases
-    {32, 768, 512, 3, fused_rb_kernel<32, 1, 8, 6, true>, "fused_rb_kernel<C32,WM1,WN8,TN6,xreg>"},
-    {64, 320, 512, 3, fused_rb_kernel<64, 2, 4, 5, true>, "fused_rb_kernel<C64,WM2,WN4,TN5,xreg>"},
-    {128, 224, 512, 3, fused_rb_kernel<128, 4, 2, 7, true>, "fused_rb_kernel<C128,WM4,WN2,TN7,xreg>"},
-    {256, 112, 512, 1, fused_rb_kernel<256, 8, 1, 7, true>, "fused_rb_kernel<C256,WM8,WN1,TN7,xreg>"},
+    {32, 768, 512, 3, fused_rb_kernel<32, 1, 8, 6, true>, "fused_rb_kernel<C32,WM1,WN8,TN6,xreg>",
+     fused_rb_kernel<32, 1, 8, 6, true, true>},
+    {64, 320, 512, 3, fused_rb_kernel<64, 2, 4, 5, true>, "fused_rb_kernel<C64,WM2,WN4,TN5,xreg>",
+     fused_rb_kernel<64, 2, 4, 5, true, true>},
+    {128, 224, 512, 3, fused_rb_kernel<128, 4, 2, 7, true>, "fused_rb_kernel<C128,WM4,WN2,TN7,xreg>",
+     fused_rb_kernel<128, 4, 2, 7, true, true>},
+    {256, 112, 512, 1, fused_rb_kernel<256, 8, 1, 7, true>, "fused_rb_kernel<C256,WM8,WN1,TN7,xreg>",
+     fused_rb_kernel<256, 8, 1, 7, true, true>},
     // 4-wave variants, kept for A/B runs (MV_FUSE bit mask: 2 -> C32, 4 -> C64, 8 -> C128)
-    {32, 768, 256, 3, fused_rb_kernel<32, 1, 4, 12, true>, "fused_rb_kernel<C32,WM1,WN4,TN12,xreg>"},
-    {64, 320, 256, 3, fused_rb_kernel<64, 2, 2, 10, true>, "fused_rb_kernel<C64,WM2,WN2,TN10,xreg>"},
-    {128, 240, 256, 1, fused_rb_kernel<128, 4, 1, 15, false>, "fused_rb_kernel<C128,WM4,WN1,TN15,pair>"},
+    {32, 768, 256, 3, fused_rb_kernel<32, 1, 4, 12, true>, "fused_rb_kernel<C32,WM1,WN4,TN12,xreg>", nullptr},
+    {64, 320, 256, 3, fused_rb_kernel<64, 2, 2, 10, true>, "fused_rb_kernel<C64,WM2,WN2,TN10,xreg>", nullptr},
+    {128, 240, 256, 1, fused_rb_kernel<128, 4, 1, 15, false>, "fused_rb_kernel<C128,WM4,WN1,TN15,pair>", nullptr},
 };
 
 static int env_or(const char* name, int dflt) {
@@ -96,8 +101,11 @@ static const StageCfg* stage_cfg_for(int Cp) {
 }
 
 int init_fused_attributes() {
-    for (const FusedCfg& f : kFused)
+    for (const FusedCfg& f : kFused) {
         MV_HIP(hipFuncSetAttribute((const void*)f.k, hipFuncAttributeMaxDynamicSharedMemorySize, kFusedMaxLds));
+        if (f.k16)
+            MV_HIP(hipFuncSetAttribute((const void*)f.k16, hipFuncAttributeMaxDynamicSharedMemorySize, kFusedMaxLds));
+    }
     for (const StageCfg& f : kStage)
         for (int a = 0; a < 2; ++a)
             for (int b = 0; b < 2; ++b)
@@ -423,7 +431,7 @@ static int launch_fused_rb(const FusedCfg& fc, const RbPair* pairs, int m0, int 
         snprintf(nm, sizeof nm, "%s k=%d", fc.name, K);
         prof->begin(stream, nm, macs * rpf);
     }
-    hipLaunchKernelGGL(fc.k, grid, dim3(fc.threads), lds, stream, p);
+    hipLaunchKernelGGL(io16 && fc.k16 ? fc.k16 : fc.k, grid, dim3(fc.threads), lds, stream, p);
     if (prof) prof->end(stream);
     MV_HIP(hipGetLastError());
     return MV_OK;
