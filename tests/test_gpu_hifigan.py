@@ -163,3 +163,24 @@ def test_edge_lengths_bf16_fused_kernels(gen_bf16):
             assert np.array_equal(p[b, :n * 256], c_oracle.pcm16(y[b, :n * 256]))
     ref = c_oracle.hifigan_forward(st, synth.HIFIGAN_V1, synth.synthetic_mel(333, 103), bf16_operands=True)
     assert snr(ref, y[3, :333 * 256]) >= 40.0
+
+
+def test_more_sequences_than_the_window_table_holds(gen_bf16):
+    """B > 1024 (the persistent kernels' per-block window table): the layer-by-layer path takes over, same results."""
+    B, T = 1030, 3
+    rng = np.random.default_rng(11)
+    lens = rng.integers(0, T + 1, size=B).astype(np.int32)
+    x = torch.from_numpy(np.stack([synth.synthetic_mel(T, 500 + (b % 7)) for b in range(B)])).cuda()
+    y = gen_bf16(x, lengths=lens.tolist())[:, 0].cpu().numpy()
+    st = synth.hifigan_state(synth.HIFIGAN_V1, 0)
+    checked = 0
+    for b in range(B):
+        n = int(lens[b])
+        assert not y[b, n * 256:].any()
+        if n == T and checked < 3:
+            # the two bf16 paths round at different points, so each is held to the oracle, not to the other
+            ref = c_oracle.hifigan_forward(st, synth.HIFIGAN_V1, synth.synthetic_mel(T, 500 + (b % 7)), bf16_operands=True)
+            err = np.sum((ref - y[b, :n * 256]).astype(np.float64) ** 2)
+            assert 10 * np.log10(np.sum(ref.astype(np.float64) ** 2) / max(err, 1e-30)) >= 40.0
+            checked += 1
+    assert checked == 3
