@@ -91,7 +91,7 @@ static const StageCfg kStage[] = {
         {fused_stage_kernel<C, WM, WN, TN, true, false>, fused_stage_kernel<C, WM, WN, TN, true, true>},   \
     }
     {32, 768, 512, MV_STAGE_VARIANTS(32, 1, 8, 6), "fused_stage_kernel<C32,WM1,WN8,TN6>"},
-    {64, 384, 512, MV_STAGE_VARIANTS(64, 2, 4, 6), "fused_stage_kernel<C64,WM2,WN4,TN6>"},
+    {64, 448, 512, MV_STAGE_VARIANTS(64, 2, 4, 7), "fused_stage_kernel<C64,WM2,WN4,TN7>"},
 };
 static const StageCfg* stage_cfg_for(int Cp) {
     static const int mode = env_or("MV_STAGE", 3);  // bit 0: C32, bit 1: C64
