@@ -3,8 +3,6 @@
 
 namespace mv {
 const char* last_error_cstr();
-int build_conv1d_layer(Layer* L, const HostTensor* w, const HostTensor* b, int Cin, int Cout, int K, int dil,
-                       int cin_pad, int cout_pad, bool bf16, int force_cfg);
 int build_convT_layer(Layer* L, const HostTensor* w, const HostTensor* b, int Cin, int Cout, int K, int u, int cin_pad,
                       int cout_pad, bool bf16, int force_cfg);
 int launch_convT(const Layer& L, const void* x, long long x_bs, int cin_stride, int rows_per_frame, float slope,

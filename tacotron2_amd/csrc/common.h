@@ -135,7 +135,7 @@ class WeightMap {
 
 // Conv1d [Cout][Cin][K] as a layer, channels zero-padded to cin_pad / cout_pad (hifigan.hip)
 int build_conv1d_layer(Layer* L, const HostTensor* w, const HostTensor* b, int Cin, int Cout, int K, int dil,
-                       int cin_pad, int cout_pad, bool bf16, int force_cfg = -1);
+                       int cin_pad, int cout_pad, bool bf16, int force_cfg = -1, bool pair_interleave = false);
 
 template <typename T>
 int upload(const std::vector<T>& host, T** dev) {

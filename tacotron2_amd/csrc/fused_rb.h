@@ -134,6 +134,29 @@ __device__ __forceinline__ unsigned long long pack4_bf16_lrelu(const f32x4& v, f
     return keep ? pack4_bf16(lrelu4(v, slope)) : 0ull;
 }
 
+// 8 consecutive channels of one row = the lane's fragments of its two M tiles (pair-interleaved channel order,
+// see fused_rb_kernel): one 16-byte LDS unit
+__device__ __forceinline__ u32x4 pack8_bf16(const f32x4& a, const f32x4& b) {
+    return u32x4{pack_bf16(a[0], a[1]), pack_bf16(a[2], a[3]), pack_bf16(b[0], b[1]), pack_bf16(b[2], b[3])};
+}
+__device__ __forceinline__ u32x4 pack8_bf16_lrelu(const f32x4& a, const f32x4& b, float slope, bool keep) {
+    return keep ? pack8_bf16(lrelu4(a, slope), lrelu4(b, slope)) : u32x4{0u, 0u, 0u, 0u};
+}
+__device__ __forceinline__ u32x4 pack8_f16_sat(const f32x4& a, const f32x4& b) {
+    f16x8 h;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        h[i] = (_Float16)fminf(fmaxf(a[i], -65504.f), 65504.f);
+        h[4 + i] = (_Float16)fminf(fmaxf(b[i], -65504.f), 65504.f);
+    }
+    return __builtin_bit_cast(u32x4, h);
+}
+__device__ __forceinline__ void unpack8_f16(const u32x4& q, f32x4& a, f32x4& b) {
+    const f16x8 h = __builtin_bit_cast(f16x8, q);
+    a = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    b = f32x4{(float)h[4], (float)h[5], (float)h[6], (float)h[7]};
+}
+
 __device__ __forceinline__ unsigned long long pack4_f16_sat(const f32x4& v) {
     f16x4 h;
 #pragma unroll
@@ -335,13 +358,18 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
     char* Y0 = Y16 + p.guardY * RS;
 
     // this lane's fragment position (n, ch) of tile (tm, tn) as a byte offset into an A / Y tile
-    const int frag0 = (wn * TN * 16 + lr) * RS + ((wm * TM) * 16 + lg * 4) * 2;
-    constexpr int FRAG_TN = 16 * RS, FRAG_TM = 32;
+    // Output channels are pair-interleaved: MFMA row r of the wave's tile tm is channel 32*wm + 8*(r>>2) + 4*tm +
+    // (r&3) (the host packs the weight rows in that order; biases stay in channel order, hifigan.hip), so a lane's two fragments of a row are 8
+    // consecutive channels = ONE 16-byte LDS unit: half as many fragment stores / loads, 2-way instead of 4-way
+    // bank conflicts on the stores, none on the loads (ablation: conflict-free fragment traffic is worth 6 %).
+    static_assert(TM == 2, "pair-interleaved channel order needs two M tiles per wave");
+    const int chl = (wm * TM) * 16 + lg * 8;  // first channel of the lane's tile-0 fragment; tile tm: + 4*tm
+    const int frag0 = (wn * TN * 16 + lr) * RS + chl * 2;
+    constexpr int FRAG_TN = 16 * RS;
 
     const long long mtile_stride = (long long)p.K * NKC * 64;
     const long long woff = (long long)(wm * TM) * mtile_stride + lane;
     const int pad2 = (p.K - 1) / 2;
-    const int chq = (wm * TM) * 16 + lg * 4;  // first channel of this lane's tm = 0 fragment
     constexpr bool io16x = XREG && IO16X;     // float16 windows come and go through LDS, next one prefetched
 
     int b = find_seq(cum_s, p.B, v);
@@ -374,20 +402,14 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
                 // The A tile holds the window as raw float16 (rows outside the sequence are zeros).  Each lane
                 // takes its own fragments as the fp32 residual and leaves bf16(lrelu(x)) in their place.
                 // (all reads first: one LDS round trip for the lot instead of one per fragment)
-                unsigned long long rawq[TM][TN];
+                u32x4 rawq[TN];
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
+                for (int tn = 0; tn < TN; ++tn) rawq[tn] = *(const u32x4*)(A0 + frag0 + tn * FRAG_TN);
 #pragma unroll
-                    for (int tm = 0; tm < TM; ++tm)
-                        rawq[tm][tn] = *(const unsigned long long*)(A0 + frag0 + tn * FRAG_TN + tm * FRAG_TM);
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                    for (int tm = 0; tm < TM; ++tm) {
-                        X[tm][tn] = unpack4_f16(rawq[tm][tn]);
-                        *(unsigned long long*)(A0 + frag0 + tn * FRAG_TN + tm * FRAG_TM) =
-                            pack4_bf16(lrelu4(X[tm][tn], 0.1f));
-                    }
+                for (int tn = 0; tn < TN; ++tn) {
+                    unpack8_f16(rawq[tn], X[0][tn], X[1][tn]);
+                    *(u32x4*)(A0 + frag0 + tn * FRAG_TN) = pack8_bf16(lrelu4(X[0][tn], 0.1f), lrelu4(X[1][tn], 0.1f));
+                }
             } else {
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) {
@@ -396,7 +418,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
                     const bool in_seq = g >= 0 && g < len;
 #pragma unroll
                     for (int tm = 0; tm < TM; ++tm) {
-                        const int ch = (wm * TM + tm) * 16 + lg * 4;
+                        const int ch = chl + 4 * tm;
                         f32x4 q = {0.f, 0.f, 0.f, 0.f};
                         if (in_seq) q = ld4(xb, (long long)g * C + ch, p.io16);
                         X[tm][tn] = q;
@@ -437,7 +459,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
             }
             f32x4 bias[TM];  // loaded ahead of the K loop: its latency hides under the MFMAs
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) bias[tm] = *(const f32x4*)(p.b1[m] + chq + tm * 16);
+            for (int tm = 0; tm < TM; ++tm) bias[tm] = *(const f32x4*)(p.b1[m] + chl + 4 * tm);
             conv_window<TM, TN>(acc, A0 + ((wn * TN * 16 + lr) - pad1) * RS + lg * 16, RS, p.K, d, NKC,
                                 (const u32x4*)p.w1[m] + woff, mtile_stride, &wpre);
             MV_LAP(tr, TR_KLOOP);
@@ -455,20 +477,15 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
             }
             if (interior) {
 #pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                    for (int tn = 0; tn < TN; ++tn)
-                        *(unsigned long long*)(Y0 + frag0 + tn * FRAG_TN + tm * FRAG_TM) =
-                            pack4_bf16(lrelu4(acc[tm][tn] + bias[tm], 0.1f));
+                for (int tn = 0; tn < TN; ++tn)
+                    *(u32x4*)(Y0 + frag0 + tn * FRAG_TN) =
+                        pack8_bf16(lrelu4(acc[0][tn] + bias[0], 0.1f), lrelu4(acc[1][tn] + bias[1], 0.1f));
             } else {
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) {
                     const int g = t0 + (wn * TN + tn) * 16 + lr;
-                    const bool keep = g >= 0 && g < len;
-#pragma unroll
-                    for (int tm = 0; tm < TM; ++tm)
-                        *(unsigned long long*)(Y0 + frag0 + tn * FRAG_TN + tm * FRAG_TM) =
-                            pack4_bf16_lrelu(acc[tm][tn] + bias[tm], 0.1f, keep);
+                    *(u32x4*)(Y0 + frag0 + tn * FRAG_TN) =
+                        pack8_bf16_lrelu(acc[0][tn] + bias[0], acc[1][tn] + bias[1], 0.1f, g >= 0 && g < len);
                 }
             }
             MV_LAP(tr, TR_EPI);
@@ -478,7 +495,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
                 if (pf) commit_raw16<C, W, NTHREADS>(raw, A0, RS, t0n, lenn);
             }
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) bias[tm] = *(const f32x4*)(p.b2[m] + chq + tm * 16);
+            for (int tm = 0; tm < TM; ++tm) bias[tm] = *(const f32x4*)(p.b2[m] + chl + 4 * tm);
             conv_window<TM, TN>(acc, Y0 + ((wn * TN * 16 + lr) - pad2) * RS + lg * 16, RS, p.K, 1, NKC,
                                 (const u32x4*)p.w2[m] + woff, mtile_stride, &wpre);
             MV_LAP(tr, TR_KLOOP);
@@ -491,12 +508,8 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
                     const int g = t0 + (wn * TN + tn) * 16 + lr;
                     const bool keep = interior || (g >= 0 && g < len);
 #pragma unroll
-                    for (int tm = 0; tm < TM; ++tm) {
-                        X[tm][tn] = (acc[tm][tn] + bias[tm]) + X[tm][tn];
-                        if (more)
-                            *(unsigned long long*)(A0 + frag0 + tn * FRAG_TN + tm * FRAG_TM) =
-                                pack4_bf16_lrelu(X[tm][tn], 0.1f, keep);
-                    }
+                    for (int tm = 0; tm < TM; ++tm) X[tm][tn] = (acc[tm][tn] + bias[tm]) + X[tm][tn];
+                    if (more) *(u32x4*)(A0 + frag0 + tn * FRAG_TN) = pack8_bf16_lrelu(X[0][tn], X[1][tn], 0.1f, keep);
                 }
             }
         }
@@ -509,10 +522,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
             MV_LAP(tr, TR_BARRIER);
             if constexpr (XREG) {
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                    for (int tm = 0; tm < TM; ++tm)
-                        *(unsigned long long*)(Y0 + frag0 + tn * FRAG_TN + tm * FRAG_TM) = pack4_f16_sat(X[tm][tn]);
+                for (int tn = 0; tn < TN; ++tn) *(u32x4*)(Y0 + frag0 + tn * FRAG_TN) = pack8_f16_sat(X[0][tn], X[1][tn]);
             }
             MV_LAP(tr, TR_EPI);
             __syncthreads();
@@ -523,7 +533,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
         } else {
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
-                const int ch = (wm * TM + tm) * 16 + lg * 4;
+                const int ch = chl + 4 * tm;
                 f32x4 bias2 = {0.f, 0.f, 0.f, 0.f};
                 if constexpr (!XREG) bias2 = *(const f32x4*)(p.b2[0] + ch);
 #pragma unroll
@@ -646,9 +656,14 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
     }
     char* A0 = A16 + p.guardA * RS;
     char* Y0 = Y16 + p.guardY * RS;
-    const int frag0 = (wn * TN * 16 + lr) * RS + ((wm * TM) * 16 + lg * 4) * 2;
-    constexpr int FRAG_TN = 16 * RS, FRAG_TM = 32;
-    const int chq = (wm * TM) * 16 + lg * 4;
+    // Output channels are pair-interleaved: MFMA row r of the wave's tile tm is channel 32*wm + 8*(r>>2) + 4*tm +
+    // (r&3) (the host packs the weight rows in that order; biases stay in channel order, hifigan.hip), so a lane's two fragments of a row are 8
+    // consecutive channels = ONE 16-byte LDS unit: half as many fragment stores / loads, 2-way instead of 4-way
+    // bank conflicts on the stores, none on the loads (ablation: conflict-free fragment traffic is worth 6 %).
+    static_assert(TM == 2, "pair-interleaved channel order needs two M tiles per wave");
+    const int chl = (wm * TM) * 16 + lg * 8;  // first channel of the lane's tile-0 fragment; tile tm: + 4*tm
+    const int frag0 = (wn * TN * 16 + lr) * RS + chl * 2;
+    constexpr int FRAG_TN = 16 * RS;
 
     int b = find_seq(cum_s, p.B, v);
     int len = (p.lengths ? p.lengths[b] : p.Tmax) * p.rows_per_frame;
@@ -693,20 +708,14 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
                 // ResBlock's last conv1 epilogue and sit in the A tile as raw float16, like a new window's)
                 // raw float16 window in the A tile -> fp32 residual registers + bf16(lrelu) in place
                 // (all reads first: one LDS round trip for the lot instead of one per fragment)
-                unsigned long long rawq[TM][TN];
+                u32x4 rawq[TN];
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
+                for (int tn = 0; tn < TN; ++tn) rawq[tn] = *(const u32x4*)(A0 + frag0 + tn * FRAG_TN);
 #pragma unroll
-                    for (int tm = 0; tm < TM; ++tm)
-                        rawq[tm][tn] = *(const unsigned long long*)(A0 + frag0 + tn * FRAG_TN + tm * FRAG_TM);
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                    for (int tm = 0; tm < TM; ++tm) {
-                        X[tm][tn] = unpack4_f16(rawq[tm][tn]);
-                        *(unsigned long long*)(A0 + frag0 + tn * FRAG_TN + tm * FRAG_TM) =
-                            pack4_bf16(lrelu4(X[tm][tn], 0.1f));
-                    }
+                for (int tn = 0; tn < TN; ++tn) {
+                    unpack8_f16(rawq[tn], X[0][tn], X[1][tn]);
+                    *(u32x4*)(A0 + frag0 + tn * FRAG_TN) = pack8_bf16(lrelu4(X[0][tn], 0.1f), lrelu4(X[1][tn], 0.1f));
+                }
             } else {
                 if (j > 0 || v != (int)blockIdx.x) __syncthreads();  // every wave is done with the tiles
 #pragma unroll
@@ -716,7 +725,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
                     const bool in_seq = g >= 0 && g < len;
 #pragma unroll
                     for (int tm = 0; tm < TM; ++tm) {
-                        const int ch = (wm * TM + tm) * 16 + lg * 4;
+                        const int ch = chl + 4 * tm;
                         f32x4 q = {0.f, 0.f, 0.f, 0.f};
                         if (in_seq) q = ld4(xb, (long long)g * C + ch, 0);
                         X[tm][tn] = q;
@@ -737,7 +746,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
                 }
                 f32x4 bias[TM];
 #pragma unroll
-                for (int tm = 0; tm < TM; ++tm) bias[tm] = *(const f32x4*)(p.b1[j][m] + chq + tm * 16);
+                for (int tm = 0; tm < TM; ++tm) bias[tm] = *(const f32x4*)(p.b1[j][m] + chl + 4 * tm);
                 conv_window<TM, TN, ADEPTH>(acc, A0 + ((wn * TN * 16 + lr) - pad1) * RS + lg * 16, RS, K, d, NKC,
                                     (const u32x4*)p.w1[j][m] + woff, mtile_stride, &wpre);
                 MV_LAP(tr, TR_KLOOP);
@@ -757,20 +766,15 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
                 }
                 if (interior) {
 #pragma unroll
-                    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                        for (int tn = 0; tn < TN; ++tn)
-                            *(unsigned long long*)(Y0 + frag0 + tn * FRAG_TN + tm * FRAG_TM) =
-                                pack4_bf16(lrelu4(acc[tm][tn] + bias[tm], 0.1f));
+                    for (int tn = 0; tn < TN; ++tn)
+                        *(u32x4*)(Y0 + frag0 + tn * FRAG_TN) =
+                            pack8_bf16(lrelu4(acc[0][tn] + bias[0], 0.1f), lrelu4(acc[1][tn] + bias[1], 0.1f));
                 } else {
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn) {
                         const int g = t0 + (wn * TN + tn) * 16 + lr;
-                        const bool keep = g >= 0 && g < len;
-#pragma unroll
-                        for (int tm = 0; tm < TM; ++tm)
-                            *(unsigned long long*)(Y0 + frag0 + tn * FRAG_TN + tm * FRAG_TM) =
-                                pack4_bf16_lrelu(acc[tm][tn] + bias[tm], 0.1f, keep);
+                        *(u32x4*)(Y0 + frag0 + tn * FRAG_TN) =
+                            pack8_bf16_lrelu(acc[0][tn] + bias[0], acc[1][tn] + bias[1], 0.1f, g >= 0 && g < len);
                     }
                 }
                 MV_LAP(tr, TR_EPI);
@@ -783,7 +787,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
                         commit_raw16<C, W, NTHREADS>(raw, A0, RS, t0, len);
                 }
 #pragma unroll
-                for (int tm = 0; tm < TM; ++tm) bias[tm] = *(const f32x4*)(p.b2[j][m] + chq + tm * 16);
+                for (int tm = 0; tm < TM; ++tm) bias[tm] = *(const f32x4*)(p.b2[j][m] + chl + 4 * tm);
                 conv_window<TM, TN, ADEPTH>(acc, Y0 + ((wn * TN * 16 + lr) - pad2) * RS + lg * 16, RS, K, 1, NKC,
                                     (const u32x4*)p.w2[j][m] + woff, mtile_stride, &wpre);
                 MV_LAP(tr, TR_KLOOP);
@@ -800,12 +804,8 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
                     const int g = t0 + (wn * TN + tn) * 16 + lr;
                     const bool keep = interior || (g >= 0 && g < len);
 #pragma unroll
-                    for (int tm = 0; tm < TM; ++tm) {
-                        X[tm][tn] = (acc[tm][tn] + bias[tm]) + X[tm][tn];
-                        if (m < 2)
-                            *(unsigned long long*)(A0 + frag0 + tn * FRAG_TN + tm * FRAG_TM) =
-                                pack4_bf16_lrelu(X[tm][tn], 0.1f, keep);
-                    }
+                    for (int tm = 0; tm < TM; ++tm) X[tm][tn] = (acc[tm][tn] + bias[tm]) + X[tm][tn];
+                    if (m < 2) *(u32x4*)(A0 + frag0 + tn * FRAG_TN) = pack8_bf16_lrelu(X[0][tn], X[1][tn], 0.1f, keep);
                 }
             }
             if (j + 1 < p.nrb) {
@@ -835,9 +835,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
             if constexpr (IO16) {
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                    for (int tm = 0; tm < TM; ++tm)
-                        *(unsigned long long*)(Y0 + frag0 + tn * FRAG_TN + tm * FRAG_TM) = pack4_f16_sat(SUM[tm][tn]);
+                    *(u32x4*)(Y0 + frag0 + tn * FRAG_TN) = pack8_f16_sat(SUM[0][tn], SUM[1][tn]);
                 MV_LAP(tr, TR_EPI);
                 __syncthreads();
                 MV_LAP(tr, TR_BARRIER);
@@ -847,7 +845,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
                 float* ob = (float*)p.out + (long long)b * p.batch_stride;
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm) {
-                    const int ch = (wm * TM + tm) * 16 + lg * 4;
+                    const int ch = chl + 4 * tm;
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn) {
                         const int n = (wn * TN + tn) * 16 + lr;
@@ -869,7 +867,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
 #pragma unroll
                 for (int k = 0; k < 7; ++k)
 #pragma unroll
-                    for (int tm = 0; tm < TM; ++tm) wk[k][tm] = *(const f32x4*)(p.post_w + k * C + chq + tm * 16);
+                    for (int tm = 0; tm < TM; ++tm) wk[k][tm] = *(const f32x4*)(p.post_w + k * C + chl + 4 * tm);
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) {
                     const int n = (wn * TN + tn) * 16 + lr;

@@ -116,6 +116,8 @@ int init_fused_attributes() {
 
 struct RbPair {
     Layer c1, c2;
+    // bf16 only: the same weights with the output channels pair-interleaved, for the fused kernels (fused_rb.h)
+    Layer c1p, c2p;
 };
 
 struct HifiganHandle : mv_handle_s {
@@ -137,6 +139,8 @@ struct HifiganHandle : mv_handle_s {
         for (auto& p : rb) {
             free_layer(&p.c1);
             free_layer(&p.c2);
+            free_layer(&p.c1p);
+            free_layer(&p.c2p);
         }
         if (post_w) (void)hipFree(post_w);
         if (post_b) (void)hipFree(post_b);
@@ -220,15 +224,19 @@ static int bias_check(const HostTensor* b, int64_t n, const char* name) {
 }
 
 // Conv1d [Cout][Cin][K] as a layer; output/ input channels padded with zeros.
+// pair_interleave: weight row 32g + 16t + r holds output channel 32g + 8(r>>2) + 4t + (r&3), the order in which the
+// fused kernels' waves (two M tiles each) own 8 consecutive channels per lane; the bias stays in channel order.
 int build_conv1d_layer(Layer* L, const HostTensor* w, const HostTensor* b, int Cin, int Cout, int K, int dil,
-                       int cin_pad, int cout_pad, bool bf16, int force_cfg) {
+                       int cin_pad, int cout_pad, bool bf16, int force_cfg, bool pair_interleave) {
     const float* wd = w->data.data();
     SrcSpec s;
     s.C = cin_pad;
     s.ktaps = K;
     s.dil = dil;
     s.pad_left = dil * (K - 1) / 2;
-    s.w = [=](int m, int tap, int c) -> float {
+    s.w = [=](int row, int tap, int c) -> float {
+        const int r = row & 15;
+        const int m = pair_interleave ? (row & ~31) + 8 * (r >> 2) + 4 * ((row >> 4) & 1) + (r & 3) : row;
         return (m < Cout && c < Cin) ? wd[((size_t)m * Cin + c) * K + tap] : 0.f;
     };
     std::vector<float> bias(cout_pad, 0.f);
@@ -347,6 +355,9 @@ static int hifigan_build(HifiganHandle* h, WeightMap& W) {
                                                  bf16)))
                         return rc;
                     (which ? pr.c2 : pr.c1).alg_macs_per_n = (double)Cc * Cc * k;
+                    if (bf16 && (rc = build_conv1d_layer(which ? &pr.c2p : &pr.c1p, cw, cb, Cc, Cc, k, which ? 1 : d, Ccp,
+                                                         Ccp, true, -1, true)))
+                        return rc;
                     macs += rows * (double)Cc * Cc * k;
                 }
             }
@@ -404,10 +415,10 @@ static int launch_fused_rb(const FusedCfg& fc, const RbPair* pairs, int m0, int 
     double macs = 0;
     for (int i = 0; i < npair; ++i) {
         const RbPair& pr = pairs[m0 + i];
-        if (pr.c1.npass != 1 || pr.c2.npass != 1) return MV_EUNSUPPORTED;  // fused kernel wants [tap][kc] order
+        if (pr.c1p.npass != 1 || pr.c2p.npass != 1) return MV_EUNSUPPORTED;  // fused kernel wants [tap][kc] order
         p.dil[i] = dils[m0 + i];
-        p.w1[i] = pr.c1.w;
-        p.w2[i] = pr.c2.w;
+        p.w1[i] = pr.c1p.w;
+        p.w2[i] = pr.c2p.w;
         p.b1[i] = pr.c1.bias;
         p.b2[i] = pr.c2.bias;
         H += pad2 * (dils[m0 + i] + 1);
@@ -464,11 +475,11 @@ static int launch_fused_stage(const StageCfg& sc, const HifiganHandle* h, int i,
         int Hj = 0;
         for (int m = 0; m < 3; ++m) {
             const RbPair& pr = h->rb[((size_t)i * c.num_kernels + j) * 3 + m];
-            if (pr.c1.npass != 1 || pr.c2.npass != 1) return MV_EUNSUPPORTED;
+            if (pr.c1p.npass != 1 || pr.c2p.npass != 1) return MV_EUNSUPPORTED;
             const int d = c.resblock_dilations[j][m];
             p.dil[j][m] = d;
-            p.w1[j][m] = pr.c1.w;
-            p.w2[j][m] = pr.c2.w;
+            p.w1[j][m] = pr.c1p.w;
+            p.w2[j][m] = pr.c2p.w;
             p.b1[j][m] = pr.c1.bias;
             p.b2[j][m] = pr.c2.bias;
             Hj += pad2 * (d + 1);
