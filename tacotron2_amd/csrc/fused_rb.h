@@ -100,15 +100,21 @@ struct FusedRbParams {
     int guardY;   // (K-1)/2
 };
 
+// acc += conv over the window (the caller initialises acc)
 template <int TM, int TN, int DEPTH = 4>
 __device__ __forceinline__ void conv_window(f32x4 (&acc)[TM][TN], const char* lds_b, int RS, int ktaps, int dil,
                                             int nkc, const u32x4* wlane, long long mtile_stride,
                                             const APre<TM, DEPTH>* pre = nullptr) {
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
     mma_pass<true, TM, TN, DEPTH>(acc, lds_b, RS, ktaps, dil, nkc, wlane, mtile_stride, pre);
+}
+
+// Biases of every conv of a launch live in LDS behind the two tiles ([conv][C] floats, filled once per persistent
+// block): a conv's accumulators START from its bias (conv2's: from residual + bias, so the K loop accumulates
+// straight into the residual registers) and the epilogues are left with lrelu + pack only.
+template <int TM>
+__device__ __forceinline__ void lds_bias(f32x4 (&bias)[TM], const float* bias_s, int conv, int C, int chl) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) bias[tm] = *(const f32x4*)(bias_s + conv * C + chl + 4 * tm);
 }
 
 // Pin the point where outstanding loads of `v` are waited for: the compiler's s_waitcnt for a value lands at
@@ -356,6 +362,11 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
     }
     char* A0 = A16 + p.guardA * RS;  // window row 0
     char* Y0 = Y16 + p.guardY * RS;
+    float* bias_s = (float*)(Y16 + (W + 2 * p.guardY) * RS);  // [2*npair][C]: b1[0], b2[0], b1[1], ...
+    for (int idx = threadIdx.x; idx < 2 * p.npair * C; idx += NTHREADS) {
+        const int cv = idx / C, ch = idx - cv * C;
+        bias_s[idx] = (cv & 1 ? p.b2[cv >> 1] : p.b1[cv >> 1])[ch];
+    }
 
     // this lane's fragment position (n, ch) of tile (tm, tn) as a byte offset into an A / Y tile
     // Output channels are pair-interleaved: MFMA row r of the wave's tile tm is channel 32*wm + 8*(r>>2) + 4*tm +
@@ -391,6 +402,9 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
     // barrier, window hand-over), so no K loop starts by waiting an L2 round trip
     APre<TM> wpre;
     wpre.request((const u32x4*)p.w1[0] + woff, mtile_stride, p.K * NKC);
+    if constexpr (!io16x) __syncthreads();  // bias_s complete (the float16 path has had its barrier above)
+    f32x4 bias[TM];  // of the conv that runs next, read while the conv before it winds down
+    lds_bias(bias, bias_s, 0, C, chl);
     for (;;) {
         const bool interior = t0 >= 0 && t0 + W <= len;  // no row of the window needs masking
         const void* xb = p.io16 ? (const void*)((const _Float16*)p.x + (long long)b * p.batch_stride)
@@ -457,13 +471,14 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
                 __syncthreads();  // A16 complete
                 MV_LAP(tr, TR_BARRIER);
             }
-            f32x4 bias[TM];  // loaded ahead of the K loop: its latency hides under the MFMAs
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) bias[tm] = *(const f32x4*)(p.b1[m] + chl + 4 * tm);
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = bias[tm];
             conv_window<TM, TN>(acc, A0 + ((wn * TN * 16 + lr) - pad1) * RS + lg * 16, RS, p.K, d, NKC,
                                 (const u32x4*)p.w1[m] + woff, mtile_stride, &wpre);
             MV_LAP(tr, TR_KLOOP);
-            settle(bias);
+            lds_bias(bias, bias_s, 2 * m + 1, C, chl);
             wpre.request((const u32x4*)p.w2[m] + woff, mtile_stride, p.K * NKC);
             // Prefetch: conv1 of the last pair is done with the A tile after the next barrier and nothing reads
             // it again until the next window, so the next window's rows are requested here (their HBM latency
@@ -478,14 +493,13 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
             if (interior) {
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
-                    *(u32x4*)(Y0 + frag0 + tn * FRAG_TN) =
-                        pack8_bf16(lrelu4(acc[0][tn] + bias[0], 0.1f), lrelu4(acc[1][tn] + bias[1], 0.1f));
+                    *(u32x4*)(Y0 + frag0 + tn * FRAG_TN) = pack8_bf16(lrelu4(acc[0][tn], 0.1f), lrelu4(acc[1][tn], 0.1f));
             } else {
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) {
                     const int g = t0 + (wn * TN + tn) * 16 + lr;
                     *(u32x4*)(Y0 + frag0 + tn * FRAG_TN) =
-                        pack8_bf16_lrelu(acc[0][tn] + bias[0], acc[1][tn] + bias[1], 0.1f, g >= 0 && g < len);
+                        pack8_bf16_lrelu(acc[0][tn], acc[1][tn], 0.1f, g >= 0 && g < len);
                 }
             }
             MV_LAP(tr, TR_EPI);
@@ -494,22 +508,34 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
             if constexpr (XREG) {
                 if (pf) commit_raw16<C, W, NTHREADS>(raw, A0, RS, t0n, lenn);
             }
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm) bias[tm] = *(const f32x4*)(p.b2[m] + chl + 4 * tm);
-            conv_window<TM, TN>(acc, Y0 + ((wn * TN * 16 + lr) - pad2) * RS + lg * 16, RS, p.K, 1, NKC,
-                                (const u32x4*)p.w2[m] + woff, mtile_stride, &wpre);
-            MV_LAP(tr, TR_KLOOP);
-            settle(bias);
-            wpre.request((const u32x4*)p.w1[m + 1 < p.npair ? m + 1 : 0] + woff, mtile_stride, p.K * NKC);
+            const int m_next = m + 1 < p.npair ? m + 1 : 0;
             if constexpr (XREG) {
-                const bool more = m + 1 < p.npair;
+                // x + bias + conv2(...): the K loop accumulates into the residual registers themselves
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn) {
-                    const int g = t0 + (wn * TN + tn) * 16 + lr;
-                    const bool keep = interior || (g >= 0 && g < len);
+                for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                    for (int tm = 0; tm < TM; ++tm) X[tm][tn] = (acc[tm][tn] + bias[tm]) + X[tm][tn];
-                    if (more) *(u32x4*)(A0 + frag0 + tn * FRAG_TN) = pack8_bf16_lrelu(X[0][tn], X[1][tn], 0.1f, keep);
+                    for (int tn = 0; tn < TN; ++tn) X[tm][tn] += bias[tm];
+                conv_window<TM, TN>(X, Y0 + ((wn * TN * 16 + lr) - pad2) * RS + lg * 16, RS, p.K, 1, NKC,
+                                    (const u32x4*)p.w2[m] + woff, mtile_stride, &wpre);
+            } else {
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = bias[tm];
+                conv_window<TM, TN>(acc, Y0 + ((wn * TN * 16 + lr) - pad2) * RS + lg * 16, RS, p.K, 1, NKC,
+                                    (const u32x4*)p.w2[m] + woff, mtile_stride, &wpre);
+            }
+            MV_LAP(tr, TR_KLOOP);
+            lds_bias(bias, bias_s, 2 * m_next, C, chl);
+            wpre.request((const u32x4*)p.w1[m_next] + woff, mtile_stride, p.K * NKC);
+            if constexpr (XREG) {
+                if (m + 1 < p.npair) {
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) {
+                        const int g = t0 + (wn * TN + tn) * 16 + lr;
+                        *(u32x4*)(A0 + frag0 + tn * FRAG_TN) =
+                            pack8_bf16_lrelu(X[0][tn], X[1][tn], 0.1f, interior || (g >= 0 && g < len));
+                    }
                 }
             }
         }
@@ -534,8 +560,6 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
                 const int ch = chl + 4 * tm;
-                f32x4 bias2 = {0.f, 0.f, 0.f, 0.f};
-                if constexpr (!XREG) bias2 = *(const f32x4*)(p.b2[0] + ch);
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) {
                     const int n = (wn * TN + tn) * 16 + lr;
@@ -546,7 +570,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
                     if constexpr (XREG)
                         q = X[tm][tn];
                     else
-                        q = (acc[tm][tn] + bias2) + ld4(xb, e, p.io16);
+                        q = acc[tm][tn] + ld4(xb, e, p.io16);
                     if (p.mode == ACC_ADD) {
                         q += ld4(ob, e, p.io16);
                     } else if (p.mode == ACC_ADD_DIV) {
@@ -656,6 +680,12 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
     }
     char* A0 = A16 + p.guardA * RS;
     char* Y0 = Y16 + p.guardY * RS;
+    float* bias_s = (float*)(Y16 + (W + 2 * p.guardY) * RS);  // [nrb][3][2][C], see lds_bias
+    for (int idx = threadIdx.x; idx < 6 * p.nrb * C; idx += NTHREADS) {
+        const int cv = idx / C, ch = idx - cv * C;
+        const int jm = cv >> 1, jj = jm / 3, mm = jm - 3 * jj;
+        bias_s[idx] = (cv & 1 ? p.b2[jj][mm] : p.b1[jj][mm])[ch];
+    }
     // Output channels are pair-interleaved: MFMA row r of the wave's tile tm is channel 32*wm + 8*(r>>2) + 4*tm +
     // (r&3) (the host packs the weight rows in that order; biases stay in channel order, hifigan.hip), so a lane's two fragments of a row are 8
     // consecutive channels = ONE 16-byte LDS unit: half as many fragment stores / loads, 2-way instead of 4-way
@@ -685,6 +715,10 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
     APre<TM, ADEPTH> wpre;  // see fused_rb_kernel
     wpre.request((const u32x4*)p.w1[0][0] + (long long)(wm * TM) * ((long long)p.K[0] * NKC * 64) + lane,
                  (long long)p.K[0] * NKC * 64, p.K[0] * NKC);
+    if constexpr (!IO16) __syncthreads();  // bias_s complete (the float16 path has had its barrier above)
+    f32x4 bias[TM];  // of the conv that runs next, see fused_rb_kernel
+    lds_bias(bias, bias_s, 0, C, chl);
+    const float inv_div = 1.f / p.div;
     for (;;) {
         const int t0 = out0 - p.H;
         const bool interior = t0 >= 0 && t0 + W <= len;
@@ -744,13 +778,14 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
                     __syncthreads();
                     MV_LAP(tr, TR_BARRIER);
                 }
-                f32x4 bias[TM];
 #pragma unroll
-                for (int tm = 0; tm < TM; ++tm) bias[tm] = *(const f32x4*)(p.b1[j][m] + chl + 4 * tm);
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = bias[tm];
                 conv_window<TM, TN, ADEPTH>(acc, A0 + ((wn * TN * 16 + lr) - pad1) * RS + lg * 16, RS, K, d, NKC,
                                     (const u32x4*)p.w1[j][m] + woff, mtile_stride, &wpre);
                 MV_LAP(tr, TR_KLOOP);
-                settle(bias);
+                lds_bias(bias, bias_s, (j * 3 + m) * 2 + 1, C, chl);
                 wpre.request((const u32x4*)p.w2[j][m] + woff, mtile_stride, K * NKC);
                 // Under the last conv1 epilogue of a ResBlock: request the rows the next ResBlock starts from -- the
                 // same window again (L2-hot), or the next window after the last ResBlock (see fused_rb_kernel).
@@ -768,13 +803,13 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn)
                         *(u32x4*)(Y0 + frag0 + tn * FRAG_TN) =
-                            pack8_bf16(lrelu4(acc[0][tn] + bias[0], 0.1f), lrelu4(acc[1][tn] + bias[1], 0.1f));
+                            pack8_bf16(lrelu4(acc[0][tn], 0.1f), lrelu4(acc[1][tn], 0.1f));
                 } else {
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn) {
                         const int g = t0 + (wn * TN + tn) * 16 + lr;
                         *(u32x4*)(Y0 + frag0 + tn * FRAG_TN) =
-                            pack8_bf16_lrelu(acc[0][tn] + bias[0], acc[1][tn] + bias[1], 0.1f, g >= 0 && g < len);
+                            pack8_bf16_lrelu(acc[0][tn], acc[1][tn], 0.1f, g >= 0 && g < len);
                     }
                 }
                 MV_LAP(tr, TR_EPI);
@@ -786,26 +821,29 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
                     else
                         commit_raw16<C, W, NTHREADS>(raw, A0, RS, t0, len);
                 }
+                // x + bias + conv2(...): the K loop accumulates into the residual registers themselves
 #pragma unroll
-                for (int tm = 0; tm < TM; ++tm) bias[tm] = *(const f32x4*)(p.b2[j][m] + chl + 4 * tm);
-                conv_window<TM, TN, ADEPTH>(acc, Y0 + ((wn * TN * 16 + lr) - pad2) * RS + lg * 16, RS, K, 1, NKC,
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) X[tm][tn] += bias[tm];
+                conv_window<TM, TN, ADEPTH>(X, Y0 + ((wn * TN * 16 + lr) - pad2) * RS + lg * 16, RS, K, 1, NKC,
                                     (const u32x4*)p.w2[j][m] + woff, mtile_stride, &wpre);
                 MV_LAP(tr, TR_KLOOP);
-                settle(bias);
                 {
                     // next conv: the next pair of this ResBlock, or the next ResBlock's (the next window's) first
                     const int jn = m < 2 ? j : (j + 1 < p.nrb ? j + 1 : 0);
                     const int mn = m < 2 ? m + 1 : 0;
                     const long long msn = (long long)p.K[jn] * NKC * 64;
+                    lds_bias(bias, bias_s, (jn * 3 + mn) * 2, C, chl);
                     wpre.request((const u32x4*)p.w1[jn][mn] + (long long)(wm * TM) * msn + lane, msn, p.K[jn] * NKC);
                 }
+                if (m < 2) {
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn) {
-                    const int g = t0 + (wn * TN + tn) * 16 + lr;
-                    const bool keep = interior || (g >= 0 && g < len);
-#pragma unroll
-                    for (int tm = 0; tm < TM; ++tm) X[tm][tn] = (acc[tm][tn] + bias[tm]) + X[tm][tn];
-                    if (m < 2) *(u32x4*)(A0 + frag0 + tn * FRAG_TN) = pack8_bf16_lrelu(X[0][tn], X[1][tn], 0.1f, keep);
+                    for (int tn = 0; tn < TN; ++tn) {
+                        const int g = t0 + (wn * TN + tn) * 16 + lr;
+                        *(u32x4*)(A0 + frag0 + tn * FRAG_TN) =
+                            pack8_bf16_lrelu(X[0][tn], X[1][tn], 0.1f, interior || (g >= 0 && g < len));
+                    }
                 }
             }
             if (j + 1 < p.nrb) {
@@ -824,7 +862,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
             for (int tn = 0; tn < TN; ++tn) {
                 SUM[tm][tn] = p.nrb > 1 ? unpack4_f16(SUM16[tm][tn]) + X[tm][tn] : X[tm][tn];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) SUM[tm][tn][i] = SUM[tm][tn][i] / p.div;
+                for (int i = 0; i < 4; ++i) SUM[tm][tn][i] = SUM[tm][tn][i] * inv_div;
             }
 
         MV_LAP(tr, TR_EPI);

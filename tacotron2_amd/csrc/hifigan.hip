@@ -430,7 +430,7 @@ static int launch_fused_rb(const FusedCfg& fc, const RbPair* pairs, int m0, int 
     p.guardA = gA;
     p.guardY = pad2;
     const int RS = fc.C * 2 + kLdsRowPad;
-    const size_t lds = (size_t)(2 * fc.W + 2 * gA + 2 * pad2) * RS;
+    const size_t lds = (size_t)(2 * fc.W + 2 * gA + 2 * pad2) * RS + (size_t)2 * npair * fc.C * 4;  // tiles + biases
     static const int pair_pct = env_or("MV_PAIR_MIN_PCT", 60);  // below this the halo recompute costs too much
     if (p.NT < 16 || lds > kFusedMaxLds || p.NT * 100 < fc.W * pair_pct || B > kMaxSeq) return MV_EUNSUPPORTED;
     const long long rows = (long long)Tmax * rpf;
@@ -502,7 +502,7 @@ static int launch_fused_stage(const StageCfg& sc, const HifiganHandle* h, int i,
     p.guardA = gA;
     p.guardY = gY;
     const int RS = sc.C * 2 + kLdsRowPad;
-    const size_t lds = (size_t)(2 * sc.W + 2 * gA + 2 * gY) * RS;
+    const size_t lds = (size_t)(2 * sc.W + 2 * gA + 2 * gY) * RS + (size_t)6 * c.num_kernels * sc.C * 4;  // + biases
     static const int min_pct = env_or("MV_STAGE_MIN_PCT", 55);
     if (lds > kFusedMaxLds || p.NT * 100 < sc.W * min_pct || B > kMaxSeq) return MV_EUNSUPPORTED;
     const long long rows = (long long)Tmax * rpf;
