@@ -428,8 +428,11 @@ __device__ __forceinline__ void store_out(const ConvOut& o, int b, long long e, 
     st4(o.ptr, eb, v, o.f16);
 }
 
+// 4-wave tiles with 64 accumulator registers fit 3 waves per SIMD (<= 168 VGPRs; the allocator lands just above
+// that on its own): a third resident block per CU is what the HBM-bound low-channel layers need (bytes in flight).
 template <bool BF16, int TM, int TN, int WM, int WN, int EPI>
-__global__ __launch_bounds__(WM* WN * 64) void conv_cl_kernel(const ConvParams p) {
+__global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(TM * TN <= 16 && WM * WN == 4 ? 3 : 2)))
+void conv_cl_kernel(const ConvParams p) {
     constexpr int MT = 16 * TM * WM, NT = 16 * TN * WN, NTHREADS = WM * WN * 64;
     constexpr int ES = BF16 ? 2 : 4;
     constexpr int CH = BF16 ? 32 : 16;

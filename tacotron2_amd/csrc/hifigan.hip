@@ -263,6 +263,12 @@ int build_convT_layer(Layer* L, const HostTensor* w, const HostTensor* b, int Ci
     std::vector<float> bias((size_t)u * cout_pad, 0.f);
     for (int p = 0; p < u; ++p)
         for (int i = 0; i < Cout; ++i) bias[(size_t)p * cout_pad + i] = b ? b->data[i] : 0.f;
+    if (force_cfg < 0 && bf16) {  // the low-channel upsamplers are HBM-bound: their tile shape is tuned on its own
+        const int M = u * cout_pad;
+        static const int c128 = env_or("MV_CFG_UPS_M128", -1), c64 = env_or("MV_CFG_UPS_M64", -1);
+        if (M == 128) force_cfg = c128;
+        if (M == 64) force_cfg = c64;
+    }
     return build_layer(L, {s}, u * cout_pad, bias, bf16, EPI_LINEAR, force_cfg);
 }
 
