@@ -38,8 +38,8 @@ static const FusedCfg kFused[] = {
     // 8 waves (two per SIMD): the second wave hides LDS / L2 latency and the epilogue phases
     {32, 768, 512, 3, fused_rb_kernel<32, 1, 8, 6, true>, "fused_rb_kernel<C32,WM1,WN8,TN6,xreg>",
      fused_rb_kernel<32, 1, 8, 6, true, true>},
-    {64, 320, 512, 3, fused_rb_kernel<64, 2, 4, 5, true>, "fused_rb_kernel<C64,WM2,WN4,TN5,xreg>",
-     fused_rb_kernel<64, 2, 4, 5, true, true>},
+    {64, 448, 512, 3, fused_rb_kernel<64, 2, 4, 7, true>, "fused_rb_kernel<C64,WM2,WN4,TN7,xreg>",
+     fused_rb_kernel<64, 2, 4, 7, true, true>},
     {128, 224, 512, 3, fused_rb_kernel<128, 4, 2, 7, true>, "fused_rb_kernel<C128,WM4,WN2,TN7,xreg>",
      fused_rb_kernel<128, 4, 2, 7, true, true>},
     {256, 112, 512, 1, fused_rb_kernel<256, 8, 1, 7, true>, "fused_rb_kernel<C256,WM8,WN1,TN7,xreg>",
@@ -73,7 +73,7 @@ static bool fuse_whole(const FusedCfg& fc, int K, const int* dils) {
     if (fc.npair < 3) return false;
     int H = 0;
     for (int m = 0; m < 3; ++m) H += (K - 1) / 2 * (dils[m] + 1);
-    static const int pct = env_or("MV_WHOLE_MIN_PCT", 70);  // NT / W at least this
+    static const int pct = env_or("MV_WHOLE_MIN_PCT", 75);  // NT / W at least this
     return (fc.W - 2 * H) * 100 >= fc.W * pct;
 }
 
@@ -455,11 +455,13 @@ static int launch_fused_rb(const FusedCfg& fc, const RbPair* pairs, int m0, int 
 }
 
 // All ResBlocks of stage `i` (+ conv_post when `wav` is given) in one launch.
-static int launch_fused_stage(const StageCfg& sc, const HifiganHandle* h, int i, const void* x, void* out,
+// The first `nrb` ResBlocks of stage `i` (+ conv_post when `wav` is given, which needs all of them) in one launch:
+// out = their sum, divided by num_kernels when the launch covers them all.
+static int launch_fused_stage(const StageCfg& sc, const HifiganHandle* h, int i, int nrb, const void* x, void* out,
                               long long bs, int rpf, void* wav, int out_format, const int32_t* lengths, int B, int Tmax,
                               hipStream_t stream, Profiler* prof, int io16) {
     const mv_hifigan_cfg& c = h->cfg;
-    if (c.num_kernels > 3) return MV_EUNSUPPORTED;
+    if (c.num_kernels > 3 || nrb < 1 || nrb > c.num_kernels || (wav && nrb != c.num_kernels)) return MV_EUNSUPPORTED;
     FusedStageParams p;
     memset(&p, 0, sizeof p);
     p.x = x;
@@ -470,11 +472,11 @@ static int launch_fused_stage(const StageCfg& sc, const HifiganHandle* h, int i,
     p.B = B;
     p.Tmax = Tmax;
     p.rows_per_frame = rpf;
-    p.nrb = c.num_kernels;
-    p.div = (float)c.num_kernels;
+    p.nrb = nrb;
+    p.div = nrb == c.num_kernels ? (float)c.num_kernels : 1.f;
     int H = 0, gA = 0, gY = 0;
     double macs = 0;
-    for (int j = 0; j < c.num_kernels; ++j) {
+    for (int j = 0; j < nrb; ++j) {
         const int K = c.resblock_kernel_sizes[j];
         const int pad2 = (K - 1) / 2;
         p.K[j] = K;
@@ -508,7 +510,7 @@ static int launch_fused_stage(const StageCfg& sc, const HifiganHandle* h, int i,
     p.guardA = gA;
     p.guardY = gY;
     const int RS = sc.C * 2 + kLdsRowPad;
-    const size_t lds = (size_t)(2 * sc.W + 2 * gA + 2 * gY) * RS + (size_t)6 * c.num_kernels * sc.C * 4;  // + biases
+    const size_t lds = (size_t)(2 * sc.W + 2 * gA + 2 * gY) * RS + (size_t)6 * nrb * sc.C * 4;  // + biases
     static const int min_pct = env_or("MV_STAGE_MIN_PCT", 55);
     if (lds > kFusedMaxLds || p.NT * 100 < sc.W * min_pct || B > kMaxSeq) return MV_EUNSUPPORTED;
     const long long rows = (long long)Tmax * rpf;
@@ -516,7 +518,9 @@ static int launch_fused_stage(const StageCfg& sc, const HifiganHandle* h, int i,
     dim3 grid((unsigned)std::min<long long>(vmax, cu_count()));
     // the persistent blocks visit only windows that exist; the waveform past a sequence's end is zero
     if (wav) MV_HIP(hipMemsetAsync(wav, 0, (size_t)B * rows * (out_format == MV_OUT_PCM16 ? 2 : 4), stream));
-    if (prof) prof->begin(stream, wav ? std::string(sc.name) + "+conv_post" : std::string(sc.name), macs * rpf);
+    if (prof)
+        prof->begin(stream, std::string(sc.name) + (wav ? "+conv_post" : nrb < c.num_kernels ? " first ResBlocks" : ""),
+                    macs * rpf);
     hipLaunchKernelGGL(sc.k[io16 ? 1 : 0][wav ? 1 : 0], grid, dim3(sc.threads), lds, stream, p);
     if (prof) prof->end(stream);
     MV_HIP(hipGetLastError());
@@ -576,20 +580,30 @@ static int hifigan_forward(HifiganHandle* h, const float* mel, const int32_t* le
             return rc;
         const FusedCfg* fc = h->precision == MV_PREC_BF16 ? fused_cfg_for(Cp) : nullptr;
         const StageCfg* sc = h->precision == MV_PREC_BF16 ? stage_cfg_for(Cp) : nullptr;
+        int j0 = 0;  // ResBlocks [0, j0) are done by a stage launch
         if (sc) {
             const bool last = i == h->nstage - 1;
-            rc = launch_fused_stage(*sc, h, i, A, ACC, bs, rpf_out, last ? wav : nullptr, out_format, lengths, B, Tmax,
-                                    stream, prof, io16);
+            // The window of a stage launch pays the halo of its widest ResBlock for all of them.  Where HBM is not
+            // the bound (C64), the widest (last) one runs pair by pair afterwards with each pair's own, smaller halo.
+            static const int split64 = env_or("MV_STAGE_SPLIT_C64", 1);
+            int nrb = c.num_kernels;
+            if (!last && Cp == 64 && split64 && fc && nrb == 3 && io16) nrb = 2;
+            rc = launch_fused_stage(*sc, h, i, nrb, A, ACC, bs, rpf_out, last ? wav : nullptr, out_format, lengths, B,
+                                    Tmax, stream, prof, io16);
             if (rc == MV_OK) {
-                cur_in = ACC;
-                rpf = rpf_out;
-                acc_idx = (acc_idx + 2) % 5;
-                post_done = last;
-                continue;
+                j0 = nrb;
+                if (nrb == c.num_kernels) {
+                    cur_in = ACC;
+                    rpf = rpf_out;
+                    acc_idx = (acc_idx + 2) % 5;
+                    post_done = last;
+                    continue;
+                }
+            } else if (rc != MV_EUNSUPPORTED) {
+                return rc;
             }
-            if (rc != MV_EUNSUPPORTED) return rc;
         }
-        for (int j = 0; j < c.num_kernels; ++j) {
+        for (int j = j0; j < c.num_kernels; ++j) {
             const float* cur = A;
             const RbPair* pairs = &h->rb[((size_t)i * c.num_kernels + j) * 3];
             const int acc_mode =
