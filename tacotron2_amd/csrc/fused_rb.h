@@ -98,6 +98,7 @@ struct FusedRbParams {
     int H;        // sum over pairs of (K-1)/2 * (dil+1)
     int guardA;   // max over pairs of dil*(K-1)/2
     int guardY;   // (K-1)/2
+    int g1;       // apron rows (see issue_apron16): dil[0]*(K-1)/2 on the float16 path, else 0
 };
 
 // acc += conv over the window (the caller initialises acc)
@@ -234,6 +235,56 @@ __device__ __forceinline__ void commit_raw16(const u32x4 (&raw)[WinLoad<C, W, NT
     }
 }
 
+// Apron: the g1 = dil*(K-1)/2 rows either side of the window that only conv1 of a ResBlock's FIRST pair reads.
+// With real rows there (instead of the zeros that stand for "outside the window") that conv's output is valid
+// on all W rows, so the first pair's dilation costs no halo: a lone pair loses (K-1)/2 rows per side instead
+// of (K-1)/2*(dil+1).  The rows land in the A tile's guard rows [-g1, 0) and [W, W+g1) as bf16(lrelu(x)), ready
+// to be an MFMA operand (no lane keeps them as residual); later pairs read whatever is there as before (finite
+// values that only reach outputs inside the halo).
+constexpr int kMaxApron = 25;  // dilation 5, K = 11
+template <int C, int NTHREADS>
+struct ApronLoad {
+    static constexpr int UPR = C / 8;
+    static constexpr int PER = (2 * kMaxApron * UPR + NTHREADS - 1) / NTHREADS;
+};
+
+template <int C, int W, int NTHREADS>
+__device__ __forceinline__ void issue_apron16(const _Float16* xb, int t0, int len, int g1,
+                                              u32x4 (&raw)[ApronLoad<C, NTHREADS>::PER]) {
+    using AL = ApronLoad<C, NTHREADS>;
+    const int tid = tid_here();
+    const int total = 2 * g1 * AL::UPR;
+#pragma unroll
+    for (int k = 0; k < AL::PER; ++k) {
+        int idx = tid + k * NTHREADS;
+        idx = idx < total ? idx : 0;
+        const int r = idx / AL::UPR, u = idx - r * AL::UPR;
+        int g = t0 + (r < g1 ? r - g1 : W + r - g1);
+        g = g < 0 ? 0 : g;
+        g = g < len ? g : len - 1;
+        raw[k] = *(const u32x4*)(xb + (long long)g * C + u * 8);
+    }
+}
+
+template <int C, int W, int NTHREADS>
+__device__ __forceinline__ void commit_apron16(const u32x4 (&raw)[ApronLoad<C, NTHREADS>::PER], char* T0, int RS,
+                                               int t0, int len, int g1) {
+    using AL = ApronLoad<C, NTHREADS>;
+    const int tid = tid_here();
+    const int total = 2 * g1 * AL::UPR;
+#pragma unroll
+    for (int k = 0; k < AL::PER; ++k) {
+        const int idx = tid + k * NTHREADS;
+        if (idx >= total) continue;
+        const int r = idx / AL::UPR, u = idx - r * AL::UPR;
+        const int row = r < g1 ? r - g1 : W + r - g1;
+        const int g = t0 + row;
+        f32x4 a, b;
+        unpack8_f16(raw[k], a, b);
+        *(u32x4*)(T0 + row * RS + u * 16) = pack8_bf16_lrelu(a, b, 0.1f, g >= 0 && g < len);
+    }
+}
+
 // Persistent blocks walk the list of (sequence, window) pairs that actually exist: cum[b] = number of
 // windows of the sequences before b (window = NT output rows), built once per block by wave 0.
 constexpr int kMaxSeq = 1024;
@@ -328,6 +379,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
     constexpr int RS = C * 2 + kLdsRowPad;
     constexpr int NKC = C / 32;
     using WL = WinLoad<C, W, NTHREADS>;
+    using AL = ApronLoad<C, NTHREADS>;
     static_assert(TM * 16 * WM == C, "C must split evenly over the M waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int cum_s[kMaxSeq + 1];
@@ -388,9 +440,11 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
     int t0 = (v - cum_s[b]) * p.NT - p.H;     // global row of window row 0
     if constexpr (XREG) {
         if constexpr (io16x) {  // the block's first window arrives synchronously, every later one is prefetched
-            u32x4 raw[WL::PER];
+            u32x4 raw[WL::PER], rawa[AL::PER];
             issue_window16<C, W, NTHREADS>((const _Float16*)p.x + (long long)b * p.batch_stride, t0, len, raw);
+            issue_apron16<C, W, NTHREADS>((const _Float16*)p.x + (long long)b * p.batch_stride, t0, len, p.g1, rawa);
             commit_raw16<C, W, NTHREADS>(raw, A0, RS, t0, len);
+            commit_apron16<C, W, NTHREADS>(rawa, A0, RS, t0, len, p.g1);
             __syncthreads();
         }
     }
@@ -484,11 +538,14 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
             // it again until the next window, so the next window's rows are requested here (their HBM latency
             // hides under this epilogue and the barrier) and dropped into the A tile before conv2 starts.
             const bool pf = XREG && io16x && has_next && m == p.npair - 1;
-            u32x4 raw[XREG ? WL::PER : 1];
+            u32x4 raw[XREG ? WL::PER : 1], rawa[XREG ? AL::PER : 1];
             if constexpr (XREG) {
-                if (pf)
+                if (pf) {
                     issue_window16<C, W, NTHREADS>((const _Float16*)p.x + (long long)bn * p.batch_stride, t0n, lenn,
                                                    raw);
+                    issue_apron16<C, W, NTHREADS>((const _Float16*)p.x + (long long)bn * p.batch_stride, t0n, lenn,
+                                                  p.g1, rawa);
+                }
             }
             if (interior) {
 #pragma unroll
@@ -506,7 +563,10 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
             __syncthreads();  // Y16 complete, A16 free
             MV_LAP(tr, TR_BARRIER);
             if constexpr (XREG) {
-                if (pf) commit_raw16<C, W, NTHREADS>(raw, A0, RS, t0n, lenn);
+                if (pf) {
+                    commit_raw16<C, W, NTHREADS>(raw, A0, RS, t0n, lenn);
+                    commit_apron16<C, W, NTHREADS>(rawa, A0, RS, t0n, lenn, p.g1);
+                }
             }
             const int m_next = m + 1 < p.npair ? m + 1 : 0;
             if constexpr (XREG) {
@@ -630,6 +690,7 @@ struct FusedStageParams {
     int H;       // halo per side (incl. 3 rows for conv_post when fused)
     int guardA;
     int guardY;
+    int g1[3];   // apron rows of each ResBlock's first pair (see issue_apron16), 0 on the float32 path
     // fused conv_post (last stage): weights [7][C] fp32, bias [1]; output [B][Tmax*rows_per_frame]
     const float* post_w;
     const float* post_b;
@@ -648,6 +709,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
     constexpr int NKC = C / 32;
     constexpr int PS = 9;  // floats per row of the conv_post partial table (7 taps, odd stride)
     using WL = WinLoad<C, W, NTHREADS>;
+    using AL = ApronLoad<C, NTHREADS>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int cum_s[kMaxSeq + 1];
 
@@ -699,9 +761,12 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
     int len = (p.lengths ? p.lengths[b] : p.Tmax) * p.rows_per_frame;
     int out0 = (v - cum_s[b]) * p.NT;
     if constexpr (IO16) {  // the block's first window arrives synchronously, every later one is prefetched
-        u32x4 raw[WL::PER];
-        issue_window16<C, W, NTHREADS>((const _Float16*)p.x + (long long)b * p.batch_stride, out0 - p.H, len, raw);
+        u32x4 raw[WL::PER], rawa[AL::PER];
+        const _Float16* xs = (const _Float16*)p.x + (long long)b * p.batch_stride;
+        issue_window16<C, W, NTHREADS>(xs, out0 - p.H, len, raw);
+        issue_apron16<C, W, NTHREADS>(xs, out0 - p.H, len, p.g1[0], rawa);
         commit_raw16<C, W, NTHREADS>(raw, A0, RS, out0 - p.H, len);
+        commit_apron16<C, W, NTHREADS>(rawa, A0, RS, out0 - p.H, len, p.g1[0]);
         __syncthreads();
     }
     MV_LAP(tr, TR_SETUP);
@@ -791,13 +856,14 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
                 // same window again (L2-hot), or the next window after the last ResBlock (see fused_rb_kernel).
                 const bool last_rb = j == p.nrb - 1;
                 const bool pf = IO16 && m == 2 && (!last_rb || has_next);
-                u32x4 raw[WL::PER];
+                u32x4 raw[WL::PER], rawa[AL::PER];
+                // (one call site each: the source is selected, not the code duplicated)
+                const _Float16* xpf = last_rb ? (const _Float16*)p.x + (long long)bn * p.batch_stride : (const _Float16*)xb;
+                const int t0pf = last_rb ? out0n - p.H : t0, lenpf = last_rb ? lenn : len;
+                const int g1pf = p.g1[last_rb ? 0 : j + 1];
                 if (pf) {
-                    if (last_rb)
-                        issue_window16<C, W, NTHREADS>((const _Float16*)p.x + (long long)bn * p.batch_stride,
-                                                       out0n - p.H, lenn, raw);
-                    else
-                        issue_window16<C, W, NTHREADS>((const _Float16*)xb, t0, len, raw);
+                    issue_window16<C, W, NTHREADS>(xpf, t0pf, lenpf, raw);
+                    issue_apron16<C, W, NTHREADS>(xpf, t0pf, lenpf, g1pf, rawa);
                 }
                 if (interior) {
 #pragma unroll
@@ -816,10 +882,8 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
                 __syncthreads();
                 MV_LAP(tr, TR_BARRIER);
                 if (pf) {
-                    if (last_rb)
-                        commit_raw16<C, W, NTHREADS>(raw, A0, RS, out0n - p.H, lenn);
-                    else
-                        commit_raw16<C, W, NTHREADS>(raw, A0, RS, t0, len);
+                    commit_raw16<C, W, NTHREADS>(raw, A0, RS, t0pf, lenpf);
+                    commit_apron16<C, W, NTHREADS>(rawa, A0, RS, t0pf, lenpf, g1pf);
                 }
                 // x + bias + conv2(...): the K loop accumulates into the residual registers themselves
 #pragma unroll

@@ -69,11 +69,12 @@ static const FusedCfg* fused_cfg_for(int Cp) {
 
 // A whole ResBlock (3 pairs) in one launch pays for itself while the halo it recomputes stays small
 // next to the window; past that the pairs run as three launches.
-static bool fuse_whole(const FusedCfg& fc, int K, const int* dils) {
+static bool fuse_whole(const FusedCfg& fc, int K, const int* dils, int io16) {
     if (fc.npair < 3) return false;
     int H = 0;
     for (int m = 0; m < 3; ++m) H += (K - 1) / 2 * (dils[m] + 1);
-    static const int pct = env_or("MV_WHOLE_MIN_PCT", 75);  // NT / W at least this
+    if (io16 && fc.k16 && dils[0] * (K - 1) / 2 <= kMaxApron) H -= dils[0] * (K - 1) / 2;  // see launch_fused_rb
+    static const int pct = env_or("MV_WHOLE_MIN_PCT", 80);  // NT / W at least this
     return (fc.W - 2 * H) * 100 >= fc.W * pct;
 }
 
@@ -427,7 +428,13 @@ static int launch_fused_rb(const FusedCfg& fc, const RbPair* pairs, int m0, int 
         p.w2[i] = pr.c2p.w;
         p.b1[i] = pr.c1.bias;
         p.b2[i] = pr.c2.bias;
-        H += pad2 * (dils[m0 + i] + 1);
+        // the float16-IO kernels give the first pair's conv1 real rows either side of the window (apron)
+        if (i == 0 && io16 && fc.k16 && dils[m0] * pad2 <= kMaxApron) {
+            p.g1 = dils[m0] * pad2;
+            H += pad2;
+        } else {
+            H += pad2 * (dils[m0 + i] + 1);
+        }
         gA = std::max(gA, dils[m0 + i] * pad2);
         macs += pr.c1.alg_macs_per_n + pr.c2.alg_macs_per_n;
     }
@@ -490,7 +497,12 @@ static int launch_fused_stage(const StageCfg& sc, const HifiganHandle* h, int i,
             p.w2[j][m] = pr.c2p.w;
             p.b1[j][m] = pr.c1.bias;
             p.b2[j][m] = pr.c2.bias;
-            Hj += pad2 * (d + 1);
+            if (m == 0 && io16 && d * pad2 <= kMaxApron) {
+                p.g1[j] = d * pad2;
+                Hj += pad2;
+            } else {
+                Hj += pad2 * (d + 1);
+            }
             gA = std::max(gA, d * pad2);
             macs += pr.c1.alg_macs_per_n + pr.c2.alg_macs_per_n;
         }
@@ -609,7 +621,7 @@ static int hifigan_forward(HifiganHandle* h, const float* mel, const int32_t* le
             const int acc_mode =
                 c.num_kernels == 1 || j == 0 ? ACC_STORE : (j == c.num_kernels - 1 ? ACC_ADD_DIV : ACC_ADD);
             const int krb = c.resblock_kernel_sizes[j];
-            if (fc && fuse_whole(*fc, krb, c.resblock_dilations[j])) {
+            if (fc && fuse_whole(*fc, krb, c.resblock_dilations[j], io16)) {
                 rc = launch_fused_rb(*fc, pairs, 0, 3, krb, c.resblock_dilations[j], A, ACC, bs, rpf_out, acc_mode,
                                      (float)c.num_kernels, lengths, B, Tmax, stream, prof, io16);
                 if (rc == MV_OK) continue;
