@@ -47,7 +47,8 @@ static const FusedCfg kFused[] = {
     // 4-wave variants, kept for A/B runs (MV_FUSE bit mask: 2 -> C32, 4 -> C64, 8 -> C128)
     {32, 768, 256, 3, fused_rb_kernel<32, 1, 4, 12, true>, "fused_rb_kernel<C32,WM1,WN4,TN12,xreg>", nullptr},
     {64, 320, 256, 3, fused_rb_kernel<64, 2, 2, 10, true>, "fused_rb_kernel<C64,WM2,WN2,TN10,xreg>", nullptr},
-    {128, 240, 256, 1, fused_rb_kernel<128, 4, 1, 15, false>, "fused_rb_kernel<C128,WM4,WN1,TN15,pair>", nullptr},
+    {128, 96, 256, 3, fused_rb_kernel<128, 4, 1, 6, true>, "fused_rb_kernel<C128,WM4,WN1,TN6,xreg>",
+     fused_rb_kernel<128, 4, 1, 6, true, true>},
 };
 
 static int env_or(const char* name, int dflt) {
@@ -449,7 +450,10 @@ static int launch_fused_rb(const FusedCfg& fc, const RbPair* pairs, int m0, int 
     const long long rows = (long long)Tmax * rpf;
     // persistent blocks, one per CU (LDS allows no more), each walking every gridDim.x-th existing window
     const long long vmax = ((rows + p.NT - 1) / p.NT) * B;
-    dim3 grid((unsigned)std::min<long long>(vmax, cu_count()));
+    // 4-wave blocks whose tiles fit half the LDS run two to a CU: one block's epilogue / barrier / window IO phases
+    // overlap the other's K loops
+    const int per_cu = fc.threads <= 256 && lds + 4608 <= 80 * 1024 ? 2 : 1;
+    dim3 grid((unsigned)std::min<long long>(vmax, (long long)per_cu * cu_count()));
     if (prof) {
         char nm[128];
         snprintf(nm, sizeof nm, "%s k=%d", fc.name, K);
