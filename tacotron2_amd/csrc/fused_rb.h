@@ -419,6 +419,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
         const int cv = idx / C, ch = idx - cv * C;
         bias_s[idx] = (cv & 1 ? p.b2[cv >> 1] : p.b1[cv >> 1])[ch];
     }
+    __syncthreads();  // guard rows zeroed before the first apron lands in them; bias_s complete
 
     // this lane's fragment position (n, ch) of tile (tm, tn) as a byte offset into an A / Y tile
     // Output channels are pair-interleaved: MFMA row r of the wave's tile tm is channel 32*wm + 8*(r>>2) + 4*tm +
@@ -456,7 +457,6 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
     // barrier, window hand-over), so no K loop starts by waiting an L2 round trip
     APre<TM> wpre;
     wpre.request((const u32x4*)p.w1[0] + woff, mtile_stride, p.K * NKC);
-    if constexpr (!io16x) __syncthreads();  // bias_s complete (the float16 path has had its barrier above)
     f32x4 bias[TM];  // of the conv that runs next, read while the conv before it winds down
     lds_bias(bias, bias_s, 0, C, chl);
     for (;;) {
@@ -748,6 +748,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
         const int jm = cv >> 1, jj = jm / 3, mm = jm - 3 * jj;
         bias_s[idx] = (cv & 1 ? p.b2[jj][mm] : p.b1[jj][mm])[ch];
     }
+    __syncthreads();  // guard rows zeroed before the first apron lands in them; bias_s complete
     // Output channels are pair-interleaved: MFMA row r of the wave's tile tm is channel 32*wm + 8*(r>>2) + 4*tm +
     // (r&3) (the host packs the weight rows in that order; biases stay in channel order, hifigan.hip), so a lane's two fragments of a row are 8
     // consecutive channels = ONE 16-byte LDS unit: half as many fragment stores / loads, 2-way instead of 4-way
@@ -780,7 +781,6 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
     APre<TM, ADEPTH> wpre;  // see fused_rb_kernel
     wpre.request((const u32x4*)p.w1[0][0] + (long long)(wm * TM) * ((long long)p.K[0] * NKC * 64) + lane,
                  (long long)p.K[0] * NKC * 64, p.K[0] * NKC);
-    if constexpr (!IO16) __syncthreads();  // bias_s complete (the float16 path has had its barrier above)
     f32x4 bias[TM];  // of the conv that runs next, see fused_rb_kernel
     lds_bias(bias, bias_s, 0, C, chl);
     const float inv_div = 1.f / p.div;
