@@ -1,51 +1,87 @@
 #!/usr/bin/env python3
-"""profiles/<tag>_traffic.json from a tools/profile_round.sh PMC summary.
+"""profiles/<tag>_traffic.json from the raw PMC passes of tools/profile_round.sh.
 
-usage: tools/traffic_json.py gpurun_out/<tag>/pmc_summary.csv <tag> [passes=3] > profiles/<tag>_traffic.json
+usage: tools/traffic_json.py <tag> <fetch counter_collection.csv> <write counter_collection.csv> > profiles/<tag>_traffic.json
 
 HBM-side bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KB / launches, FETCH_SIZE doubled as
-MI355X_MICROARCH.md prescribes for gfx950 (wide reads count half); the summary adds the dispatches of all PMC
-passes, each counter comes from one of them.  Keys are the library's own kernel names (what bench.py's
-`roofline.kernel` carries), so bench.py can attach the measured traffic to the dominant kernel.
+MI355X_MICROARCH.md prescribes for gfx950 (wide reads count half).  Keys are the library's own kernel names
+(what bench.py's `roofline.kernel` carries, e.g. "fused_rb_kernel<C128,WM4,WN2,TN7,xreg> k=11"), so bench.py
+can attach the measured traffic to the dominant kernel.
+
+rocprofv3 sees one symbol for all ResBlock kernel sizes of `fused_rb_kernel<C...>`; they are told apart by the
+position of the dispatch within a step, which for HiFi-GAN V1 (resblock_kernel_sizes 3/7/11, hifigan.hip
+launch order) is fixed: C256 runs 3 + 3 + 3 pair launches, C128 one whole k=3 launch + 3 + 3, C64 three k=11
+pair launches after its stage launch.
 """
+import collections
+import csv
 import json
 import re
 import sys
 
+# launches per step of each ResBlock kernel size, in launch order
+RB_PATTERN = {256: [(3, 3), (7, 3), (11, 3)], 128: [(3, 1), (7, 3), (11, 3)], 64: [(11, 3)], 32: []}
 
-def lib_name(rocprof_name):
-    m = re.match(r"fused_rb_kernel<(\d+), (\d+), (\d+), (\d+), (true|false)", rocprof_name)
+
+def lib_name(rocprof_name, nth):
+    """library name of the nth dispatch (0-based, in order) of a rocprof kernel symbol; None = not a fused kernel"""
+    m = re.search(r"fused_rb_kernel<(\d+), (\d+), (\d+), (\d+), (true|false)", rocprof_name)
     if m:
         c, wm, wn, tn, xreg = m.groups()
-        return f"fused_rb_kernel<C{c},WM{wm},WN{wn},TN{tn},{'xreg' if xreg == 'true' else 'pair'}>"
-    m = re.match(r"fused_stage_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (true|false)>", rocprof_name)
+        base = f"fused_rb_kernel<C{c},WM{wm},WN{wn},TN{tn},{'xreg' if xreg == 'true' else 'pair'}>"
+        pat = RB_PATTERN.get(int(c)) or []
+        per_step = sum(n for _, n in pat)
+        if per_step:
+            i = nth % per_step
+            for k, n in pat:
+                if i < n:
+                    return f"{base} k={k}"
+                i -= n
+        return base
+    m = re.search(r"fused_stage_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (true|false)>", rocprof_name)
     if m:
         c, wm, wn, tn, _, post = m.groups()
-        return f"fused_stage_kernel<C{c},WM{wm},WN{wn},TN{tn}>" + ("+conv_post" if post == "true" else "")
+        base = f"fused_stage_kernel<C{c},WM{wm},WN{wn},TN{tn}>"
+        return base + ("+conv_post" if post == "true" else " first ResBlocks" if c == "64" else "")
     return None
 
 
+def per_dispatch(path, counter):
+    """[(kernel symbol, value)] in dispatch order"""
+    rows = {}
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] == counter:
+                rows[int(r["Dispatch_Id"])] = (r["Kernel_Name"], float(r["Counter_Value"]))
+    return [rows[k] for k in sorted(rows)]
+
+
+def by_name(path, counter):
+    seen = collections.Counter()
+    out = collections.defaultdict(list)
+    for sym, val in per_dispatch(path, counter):
+        name = lib_name(sym, seen[sym])
+        seen[sym] += 1
+        if name:
+            out[name].append(val)
+    return out
+
+
 def main():
-    path, tag = sys.argv[1], sys.argv[2]
-    passes = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-    lines = open(path).read().strip().split("\n")
-    cols = lines[0].split(",")
-    n = len(cols) - 1
+    tag, fetch_csv, write_csv = sys.argv[1:4]
+    fetch, write = by_name(fetch_csv, "FETCH_SIZE"), by_name(write_csv, "WRITE_SIZE")
     out = {
-        "_note": f"HBM-side bytes per launch from profiles/{tag}_pmc_summary.csv: (2*FETCH_SIZE + WRITE_SIZE) KB / "
-        "launches (FETCH_SIZE doubled per MI355X_MICROARCH.md, the gfx950 wide-read correction; Infinity-Cache hits "
-        "are included). Measured on bench.py's default batch; bench.py reports it for the dominant kernel when the "
-        "name matches."
+        "_note": f"HBM-side bytes per launch from the PMC passes of profiles/{tag}_* (tools/traffic_json.py): "
+        "(2*FETCH_SIZE + WRITE_SIZE) KB averaged over the launches of each kernel (FETCH_SIZE doubled per "
+        "MI355X_MICROARCH.md, the gfx950 wide-read correction; Infinity-Cache hits are included). Measured on "
+        "bench.py's default batch; bench.py reports it for the dominant kernel when the name matches."
     }
-    for ln in lines[1:]:
-        parts = ln.rsplit(",", n)  # kernel names contain commas
-        row = dict(zip(cols[1:], parts[1:]))
-        name = lib_name(parts[0])
-        if not name:
+    for name in fetch:
+        if name not in write or len(write[name]) != len(fetch[name]):
             continue
-        launches = int(row["dispatches"]) // passes
-        kb = 2 * float(row["FETCH_SIZE"]) + float(row["WRITE_SIZE"])
-        out[name] = {"bytes_per_launch": int(kb * 1024 / launches), "dispatches": launches}
+        n = len(fetch[name])
+        kb = (2 * sum(fetch[name]) + sum(write[name])) / n
+        out[name] = {"bytes_per_launch": int(kb * 1024), "dispatches": n}
     json.dump(out, sys.stdout, indent=1)
     print()
 
