@@ -8,7 +8,7 @@ root=$(pwd)
 out=$root/gpurun_out/$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+BENCH="python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline $BENCH_ARGS"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$out/stats" -o st --output-format csv -- $BENCH > "$out/stats.log" 2>&1
 cp $(find "$out/stats" -name '*kernel_stats.csv' | head -1) "$out/kernel_stats.csv"
 pass() {  # name counters...
