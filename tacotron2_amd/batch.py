@@ -66,11 +66,16 @@ def shard_buckets(buckets, world):
     return shards, loads
 
 
-def pad_bucket(mels, bucket, pad_value=synth.MEL_PAD_VALUE, device=None):
-    """Right-pad the bucket's mels ([80,T] tensors / arrays) to [B,80,Tmax] plus an int32 length vector."""
+def pad_bucket(mels, bucket, pad_value=synth.MEL_PAD_VALUE, device=None, into=None):
+    """Right-pad the bucket's mels ([80,T] tensors / arrays) to [B,80,Tmax] plus an int32 length vector.
+    `into`: a flat float32 tensor (e.g. a reusable pinned staging buffer) to build the batch in."""
     B, tmax = len(bucket.indices), bucket.tmax
     n_mels = int(mels[bucket.indices[0]].shape[0])
-    x = torch.full((B, n_mels, tmax), float(pad_value), dtype=torch.float32)
+    if into is not None:
+        x = into[: B * n_mels * tmax].view(B, n_mels, tmax)
+        x.fill_(float(pad_value))
+    else:
+        x = torch.full((B, n_mels, tmax), float(pad_value), dtype=torch.float32)
     for b, (i, T) in enumerate(zip(bucket.indices, bucket.lengths)):
         x[b, :, :T] = torch.as_tensor(mels[i], dtype=torch.float32)[:, :T]
     lengths = torch.tensor(bucket.lengths, dtype=torch.int32)
@@ -155,35 +160,41 @@ def synthesize_shard(vocoder, mels, lengths=None, rank=0, world=1, device=None, 
         dev = torch.device(device)
         compute = torch.cuda.current_stream(dev)
         copy_in, copy_out = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
-        pool = ThreadPoolExecutor(1)
+        # two host workers: one pads the next bucket into a pinned slot, one hands the previous bucket's audio to
+        # the caller; the main thread only launches.  Three slots each way: slot k is free again once bucket k's
+        # upload (in) / hand-over (out) is done, which the worker that reuses it waits for.
+        pool_in, pool_out = ThreadPoolExecutor(1), ThreadPoolExecutor(1)
         csum = torch.zeros((), dtype=torch.float64, device=dev)
         odt = torch.int16 if out == "pcm16" else torch.float32
-        cap = max((len(buckets[bi].indices) * buckets[bi].tmax for bi in mine), default=0) * hop
-        slots = [torch.empty(cap, dtype=odt).pin_memory() for _ in range(2)] if (d2h and cap) else []
+        NS = 3
+        cap = max((len(buckets[bi].indices) * buckets[bi].tmax for bi in mine), default=0)
+        n_mels = int(mels[0].shape[0]) if (device_mels is None and len(mels)) else 80
+        out_slots = [torch.empty(cap * hop, dtype=odt).pin_memory() for _ in range(NS)] if (d2h and cap) else []
+        in_slots = ([torch.empty(cap * n_mels, dtype=torch.float32).pin_memory() for _ in range(NS)]
+                    if (device_mels is None and cap) else [])
+        in_free = [None] * NS   # event: the upload that last read the slot
+        out_free = [None] * NS  # future: the hand-over that last read the slot
 
-        def prep(bi):
+        def prep(k, bi):
             if device_mels is not None:
                 return None
-            x, lens = pad_bucket(mels, buckets[bi])
-            return x.pin_memory(), lens
+            if in_free[k % NS] is not None:
+                in_free[k % NS].synchronize()
+            return pad_bucket(mels, buckets[bi], into=in_slots[k % NS])
 
-        def finalize(p):
-            if p is None:
-                return
-            bk, hb, ev = p
+        def finalize(bk, hb, ev):
             ev.synchronize()
             if keep_audio:
                 host = hb.numpy()
                 for b, (i, T) in enumerate(zip(bk.indices, bk.lengths)):
                     results[i] = host[b, : T * hop].copy()
 
-        fut = pool.submit(prep, mine[0]) if mine else None
-        pending = None
+        fut = pool_in.submit(prep, 0, mine[0]) if mine else None
         for k, bi in enumerate(mine):
             bk = buckets[bi]
             staged = fut.result()
             if k + 1 < len(mine):
-                fut = pool.submit(prep, mine[k + 1])
+                fut = pool_in.submit(prep, k + 1, mine[k + 1])
             if device_mels is not None:
                 x, lens = device_mel_bucket(bk, device_mels, dev)
             else:
@@ -191,6 +202,7 @@ def synthesize_shard(vocoder, mels, lengths=None, rank=0, world=1, device=None, 
                 with torch.cuda.stream(copy_in):
                     x = xh.to(dev, non_blocking=True)
                     ev_in = copy_in.record_event()
+                in_free[k % NS] = ev_in
                 compute.wait_event(ev_in)
                 x.record_stream(compute)
             wav = vocoder(x, lengths=lens, out=out)
@@ -199,18 +211,22 @@ def synthesize_shard(vocoder, mels, lengths=None, rank=0, world=1, device=None, 
             if d2h:
                 ev_c = compute.record_event()
                 B, n = wav.shape[0], wav.shape[-1]
-                hb = slots[k & 1][: B * n].view(B, n)
-                finalize(pending)  # bucket k-1 is on the host: its slot is the one bucket k+1 will reuse
+                if out_free[k % NS] is not None:
+                    out_free[k % NS].result()  # bucket k-3 has been handed over: its slot is free
+                hb = out_slots[k % NS][: B * n].view(B, n)
                 with torch.cuda.stream(copy_out):
                     copy_out.wait_event(ev_c)
                     hb.copy_(wav.view(B, n), non_blocking=True)
                     wav.record_stream(copy_out)
                     ev_o = copy_out.record_event()
-                pending = (bk, hb, ev_o)
+                out_free[k % NS] = pool_out.submit(finalize, bk, hb, ev_o)
             stats.utterances += len(bk.indices)
             stats.frames += bk.cost
-        finalize(pending)
-        pool.shutdown()
+        for f in out_free:
+            if f is not None:
+                f.result()
+        pool_in.shutdown()
+        pool_out.shutdown()
         sync()
         stats.checksum = float(csum.item())
     sync()
