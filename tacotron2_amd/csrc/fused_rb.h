@@ -567,6 +567,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
                     commit_raw16<C, W, NTHREADS>(raw, A0, RS, t0n, lenn);
                     commit_apron16<C, W, NTHREADS>(rawa, A0, RS, t0n, lenn, p.g1);
                 }
+                MV_LAP(tr, TR_LOADX);
             }
             const int m_next = m + 1 < p.npair ? m + 1 : 0;
             if constexpr (XREG) {
@@ -885,6 +886,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
                     commit_raw16<C, W, NTHREADS>(raw, A0, RS, t0pf, lenpf);
                     commit_apron16<C, W, NTHREADS>(rawa, A0, RS, t0pf, lenpf, g1pf);
                 }
+                MV_LAP(tr, TR_LOADX);
                 // x + bias + conv2(...): the K loop accumulates into the residual registers themselves
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
