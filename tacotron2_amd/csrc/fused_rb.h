@@ -371,7 +371,9 @@ __device__ __forceinline__ void store_window16(_Float16* ob, const char* T0, int
 
 // IO16X: float16 window IO through LDS with prefetch (XREG kernels, p.io16 set) -- compile-time for the same
 // reason as in fused_stage_kernel (one variant per function keeps the register allocator from spilling).
-template <int C, int WM, int WN, int TN, bool XREG, bool IO16X = false>
+// ONE: a single (conv, conv) pair per launch, known at compile time (most launches: the pair loop and the
+// hand-over to a next pair drop out).
+template <int C, int WM, int WN, int TN, bool XREG, bool IO16X = false, bool ONE = false>
 __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbParams p) {
     constexpr int TM = C / 16 / WM;
     constexpr int W = 16 * TN * WN;
@@ -381,6 +383,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
     using WL = WinLoad<C, W, NTHREADS>;
     using AL = ApronLoad<C, NTHREADS>;
     static_assert(TM * 16 * WM == C, "C must split evenly over the M waves");
+    const int npair = ONE ? 1 : p.npair;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int cum_s[kMaxSeq + 1];
 
@@ -415,7 +418,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
     char* A0 = A16 + p.guardA * RS;  // window row 0
     char* Y0 = Y16 + p.guardY * RS;
     float* bias_s = (float*)(Y16 + (W + 2 * p.guardY) * RS);  // [2*npair][C]: b1[0], b2[0], b1[1], ...
-    for (int idx = threadIdx.x; idx < 2 * p.npair * C; idx += NTHREADS) {
+    for (int idx = threadIdx.x; idx < 2 * npair * C; idx += NTHREADS) {
         const int cv = idx / C, ch = idx - cv * C;
         bias_s[idx] = (cv & 1 ? p.b2[cv >> 1] : p.b1[cv >> 1])[ch];
     }
@@ -517,7 +520,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
             t0n = (vn - cum_s[bn]) * p.NT - p.H;
         }
 
-        for (int m = 0; m < p.npair; ++m) {
+        for (int m = 0; m < npair; ++m) {
             const int d = p.dil[m];
             const int pad1 = d * (p.K - 1) / 2;
             if (m > 0) {
@@ -537,7 +540,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
             // Prefetch: conv1 of the last pair is done with the A tile after the next barrier and nothing reads
             // it again until the next window, so the next window's rows are requested here (their HBM latency
             // hides under this epilogue and the barrier) and dropped into the A tile before conv2 starts.
-            const bool pf = XREG && io16x && has_next && m == p.npair - 1;
+            const bool pf = XREG && io16x && has_next && m == npair - 1;
             u32x4 raw[XREG ? WL::PER : 1], rawa[XREG ? AL::PER : 1];
             if constexpr (XREG) {
                 if (pf) {
@@ -569,7 +572,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
                 }
                 MV_LAP(tr, TR_LOADX);
             }
-            const int m_next = m + 1 < p.npair ? m + 1 : 0;
+            const int m_next = m + 1 < npair ? m + 1 : 0;
             if constexpr (XREG) {
                 // x + bias + conv2(...): the K loop accumulates into the residual registers themselves
 #pragma unroll
@@ -590,7 +593,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
             lds_bias(bias, bias_s, 2 * m_next, C, chl);
             wpre.request((const u32x4*)p.w1[m_next] + woff, mtile_stride, p.K * NKC);
             if constexpr (XREG) {
-                if (m + 1 < p.npair) {
+                if (m + 1 < npair) {
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn) {
                         const int g = t0 + (wn * TN + tn) * 16 + lr;
@@ -656,7 +659,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
             MV_LAP(tr, TR_BARRIER);
         }
     }
-    MV_FLUSH(tr, (C << 16) | (p.K << 8) | p.npair);
+    MV_FLUSH(tr, (C << 16) | (p.K << 8) | npair);
 }
 
 // ---------------------------------------------------------------------------------------------

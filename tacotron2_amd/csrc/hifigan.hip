@@ -32,23 +32,24 @@ struct FusedCfg {
     FusedKernel k;
     const char* name;
     FusedKernel k16;  // float16-IO variant (XREG kernels), null if there is none
+    FusedKernel k16_one;  // ... specialised for one pair per launch, null if there is none
 };
 //                         C   WM WN TN  XREG
 static const FusedCfg kFused[] = {
     // 8 waves (two per SIMD): the second wave hides LDS / L2 latency and the epilogue phases
     {32, 768, 512, 3, fused_rb_kernel<32, 1, 8, 6, true>, "fused_rb_kernel<C32,WM1,WN8,TN6,xreg>",
-     fused_rb_kernel<32, 1, 8, 6, true, true>},
+     fused_rb_kernel<32, 1, 8, 6, true, true>, fused_rb_kernel<32, 1, 8, 6, true, true, true>},
     {64, 448, 512, 3, fused_rb_kernel<64, 2, 4, 7, true>, "fused_rb_kernel<C64,WM2,WN4,TN7,xreg>",
-     fused_rb_kernel<64, 2, 4, 7, true, true>},
+     fused_rb_kernel<64, 2, 4, 7, true, true>, fused_rb_kernel<64, 2, 4, 7, true, true, true>},
     {128, 224, 512, 3, fused_rb_kernel<128, 4, 2, 7, true>, "fused_rb_kernel<C128,WM4,WN2,TN7,xreg>",
-     fused_rb_kernel<128, 4, 2, 7, true, true>},
+     fused_rb_kernel<128, 4, 2, 7, true, true>, fused_rb_kernel<128, 4, 2, 7, true, true, true>},
     {256, 112, 512, 1, fused_rb_kernel<256, 8, 1, 7, true>, "fused_rb_kernel<C256,WM8,WN1,TN7,xreg>",
-     fused_rb_kernel<256, 8, 1, 7, true, true>},
+     fused_rb_kernel<256, 8, 1, 7, true, true>, fused_rb_kernel<256, 8, 1, 7, true, true, true>},
     // 4-wave variants, kept for A/B runs (MV_FUSE bit mask: 2 -> C32, 4 -> C64, 8 -> C128)
-    {32, 768, 256, 3, fused_rb_kernel<32, 1, 4, 12, true>, "fused_rb_kernel<C32,WM1,WN4,TN12,xreg>", nullptr},
-    {64, 320, 256, 3, fused_rb_kernel<64, 2, 2, 10, true>, "fused_rb_kernel<C64,WM2,WN2,TN10,xreg>", nullptr},
+    {32, 768, 256, 3, fused_rb_kernel<32, 1, 4, 12, true>, "fused_rb_kernel<C32,WM1,WN4,TN12,xreg>", nullptr, nullptr},
+    {64, 320, 256, 3, fused_rb_kernel<64, 2, 2, 10, true>, "fused_rb_kernel<C64,WM2,WN2,TN10,xreg>", nullptr, nullptr},
     {128, 96, 256, 3, fused_rb_kernel<128, 4, 1, 6, true>, "fused_rb_kernel<C128,WM4,WN1,TN6,xreg>",
-     fused_rb_kernel<128, 4, 1, 6, true, true>},
+     fused_rb_kernel<128, 4, 1, 6, true, true>, nullptr},
 };
 
 static int env_or(const char* name, int dflt) {
@@ -107,6 +108,9 @@ int init_fused_attributes() {
         MV_HIP(hipFuncSetAttribute((const void*)f.k, hipFuncAttributeMaxDynamicSharedMemorySize, kFusedMaxLds));
         if (f.k16)
             MV_HIP(hipFuncSetAttribute((const void*)f.k16, hipFuncAttributeMaxDynamicSharedMemorySize, kFusedMaxLds));
+        if (f.k16_one)
+            MV_HIP(hipFuncSetAttribute((const void*)f.k16_one, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       kFusedMaxLds));
     }
     for (const StageCfg& f : kStage)
         for (int a = 0; a < 2; ++a)
@@ -459,7 +463,10 @@ static int launch_fused_rb(const FusedCfg& fc, const RbPair* pairs, int m0, int 
         snprintf(nm, sizeof nm, "%s k=%d", fc.name, K);
         prof->begin(stream, nm, macs * rpf);
     }
-    hipLaunchKernelGGL(io16 && fc.k16 ? fc.k16 : fc.k, grid, dim3(fc.threads), lds, stream, p);
+    static const int one_on = env_or("MV_RB_ONE", 1);
+    FusedKernel kern = io16 && fc.k16 ? fc.k16 : fc.k;
+    if (io16 && npair == 1 && fc.k16_one && one_on) kern = fc.k16_one;
+    hipLaunchKernelGGL(kern, grid, dim3(fc.threads), lds, stream, p);
     if (prof) prof->end(stream);
     MV_HIP(hipGetLastError());
     return MV_OK;
