@@ -16,9 +16,8 @@
 // batch-1 call sees.  HBM traffic per ResBlock drops from 15 activation passes (6 convs unfused)
 // to ~2.3 with NPAIR = 3, ~7 with NPAIR = 1.
 //
-// XREG = true : the fp32 residual stream x lives in registers in MFMA accumulator layout (each
-//               wave keeps x for exactly the (channel, row) tiles it accumulates), NPAIR may be 3.
-// XREG = false: NPAIR must be 1; x is staged once (coalesced) and re-read from L2 for the residual.
+// The fp32 residual stream x lives in registers in MFMA accumulator layout (each wave keeps x for exactly the
+// (channel, row) tiles it accumulates).
 //
 // Waves: WM x WN; wave (wm, wn) owns M tiles [wm*TM, +TM) (TM = C/16/WM) and N tiles [wn*TN, +TN).
 // Weights stream L2 -> registers in A-fragment order exactly as in conv_mfma.h.
@@ -369,11 +368,11 @@ __device__ __forceinline__ void store_window16(_Float16* ob, const char* T0, int
     }
 }
 
-// IO16X: float16 window IO through LDS with prefetch (XREG kernels, p.io16 set) -- compile-time for the same
+// IO16X: float16 window IO through LDS with prefetch (p.io16 set) -- compile-time for the same
 // reason as in fused_stage_kernel (one variant per function keeps the register allocator from spilling).
 // ONE: a single (conv, conv) pair per launch, known at compile time (most launches: the pair loop and the
 // hand-over to a next pair drop out).
-template <int C, int WM, int WN, int TN, bool XREG, bool IO16X = false, bool ONE = false>
+template <int C, int WM, int WN, int TN, bool IO16X = false, bool ONE = false>
 __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbParams p) {
     constexpr int TM = C / 16 / WM;
     constexpr int W = 16 * TN * WN;
@@ -437,24 +436,22 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
     const long long mtile_stride = (long long)p.K * NKC * 64;
     const long long woff = (long long)(wm * TM) * mtile_stride + lane;
     const int pad2 = (p.K - 1) / 2;
-    constexpr bool io16x = XREG && IO16X;     // float16 windows come and go through LDS, next one prefetched
+    constexpr bool io16x = IO16X;             // float16 windows come and go through LDS, next one prefetched
 
     int b = find_seq(cum_s, p.B, v);
     int len = (p.lengths ? p.lengths[b] : p.Tmax) * p.rows_per_frame;
     int t0 = (v - cum_s[b]) * p.NT - p.H;     // global row of window row 0
-    if constexpr (XREG) {
-        if constexpr (io16x) {  // the block's first window arrives synchronously, every later one is prefetched
-            u32x4 raw[WL::PER], rawa[AL::PER];
-            issue_window16<C, W, NTHREADS>((const _Float16*)p.x + (long long)b * p.batch_stride, t0, len, raw);
-            issue_apron16<C, W, NTHREADS>((const _Float16*)p.x + (long long)b * p.batch_stride, t0, len, p.g1, rawa);
-            commit_raw16<C, W, NTHREADS>(raw, A0, RS, t0, len);
-            commit_apron16<C, W, NTHREADS>(rawa, A0, RS, t0, len, p.g1);
-            __syncthreads();
-        }
+    if constexpr (io16x) {  // the block's first window arrives synchronously, every later one is prefetched
+        u32x4 raw[WL::PER], rawa[AL::PER];
+        issue_window16<C, W, NTHREADS>((const _Float16*)p.x + (long long)b * p.batch_stride, t0, len, raw);
+        issue_apron16<C, W, NTHREADS>((const _Float16*)p.x + (long long)b * p.batch_stride, t0, len, p.g1, rawa);
+        commit_raw16<C, W, NTHREADS>(raw, A0, RS, t0, len);
+        commit_apron16<C, W, NTHREADS>(rawa, A0, RS, t0, len, p.g1);
+        __syncthreads();
     }
     MV_LAP(tr, TR_SETUP);
 
-    f32x4 X[XREG ? TM : 1][XREG ? TN : 1];
+    f32x4 X[TM][TN];  // the residual stream
     f32x4 acc[TM][TN];
     // the first weight fragments of every conv are requested while the conv before it winds down (epilogue,
     // barrier, window hand-over), so no K loop starts by waiting an L2 round trip
@@ -468,43 +465,33 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
                                 : (const void*)((const float*)p.x + (long long)b * p.batch_stride);
         void* ob = p.io16 ? (void*)((_Float16*)p.out + (long long)b * p.batch_stride)
                           : (void*)((float*)p.out + (long long)b * p.batch_stride);
-        if constexpr (XREG) {
-            if constexpr (io16x) {
-                // The A tile holds the window as raw float16 (rows outside the sequence are zeros).  Each lane
-                // takes its own fragments as the fp32 residual and leaves bf16(lrelu(x)) in their place.
-                // (all reads first: one LDS round trip for the lot instead of one per fragment)
-                u32x4 rawq[TN];
+        if constexpr (io16x) {
+            // The A tile holds the window as raw float16 (rows outside the sequence are zeros).  Each lane
+            // takes its own fragments as the fp32 residual and leaves bf16(lrelu(x)) in their place.
+            // (all reads first: one LDS round trip for the lot instead of one per fragment)
+            u32x4 rawq[TN];
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn) rawq[tn] = *(const u32x4*)(A0 + frag0 + tn * FRAG_TN);
+            for (int tn = 0; tn < TN; ++tn) rawq[tn] = *(const u32x4*)(A0 + frag0 + tn * FRAG_TN);
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn) {
-                    unpack8_f16(rawq[tn], X[0][tn], X[1][tn]);
-                    *(u32x4*)(A0 + frag0 + tn * FRAG_TN) = pack8_bf16(lrelu4(X[0][tn], 0.1f), lrelu4(X[1][tn], 0.1f));
-                }
-            } else {
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn) {
-                    const int n = (wn * TN + tn) * 16 + lr;
-                    const int g = t0 + n;
-                    const bool in_seq = g >= 0 && g < len;
-#pragma unroll
-                    for (int tm = 0; tm < TM; ++tm) {
-                        const int ch = chl + 4 * tm;
-                        f32x4 q = {0.f, 0.f, 0.f, 0.f};
-                        if (in_seq) q = ld4(xb, (long long)g * C + ch, p.io16);
-                        X[tm][tn] = q;
-                        *(unsigned long long*)(A0 + n * RS + ch * 2) = pack4_bf16_lrelu(q, 0.1f, in_seq);
-                    }
-                }
+            for (int tn = 0; tn < TN; ++tn) {
+                unpack8_f16(rawq[tn], X[0][tn], X[1][tn]);
+                *(u32x4*)(A0 + frag0 + tn * FRAG_TN) = pack8_bf16(lrelu4(X[0][tn], 0.1f), lrelu4(X[1][tn], 0.1f));
             }
         } else {
-            ConvPass cp;
-            cp.row_stride = C;
-            cp.cin_off = 0;
-            cp.cb = C;
-            cp.slope = 0.1f;
-            cp.src_f16 = p.io16;
-            stage_tile<true, NTHREADS>(A0, cp, xb, t0, W, len, RS);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int n = (wn * TN + tn) * 16 + lr;
+                const int g = t0 + n;
+                const bool in_seq = g >= 0 && g < len;
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    const int ch = chl + 4 * tm;
+                    f32x4 q = {0.f, 0.f, 0.f, 0.f};
+                    if (in_seq) q = ld4(xb, (long long)g * C + ch, p.io16);
+                    X[tm][tn] = q;
+                    *(unsigned long long*)(A0 + n * RS + ch * 2) = pack4_bf16_lrelu(q, 0.1f, in_seq);
+                }
+            }
         }
         MV_LAP(tr, TR_LOADX);
         __syncthreads();  // A16 complete
@@ -540,15 +527,12 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
             // Prefetch: conv1 of the last pair is done with the A tile after the next barrier and nothing reads
             // it again until the next window, so the next window's rows are requested here (their HBM latency
             // hides under this epilogue and the barrier) and dropped into the A tile before conv2 starts.
-            const bool pf = XREG && io16x && has_next && m == npair - 1;
-            u32x4 raw[XREG ? WL::PER : 1], rawa[XREG ? AL::PER : 1];
-            if constexpr (XREG) {
-                if (pf) {
-                    issue_window16<C, W, NTHREADS>((const _Float16*)p.x + (long long)bn * p.batch_stride, t0n, lenn,
-                                                   raw);
-                    issue_apron16<C, W, NTHREADS>((const _Float16*)p.x + (long long)bn * p.batch_stride, t0n, lenn,
-                                                  p.g1, rawa);
-                }
+            const bool pf = io16x && has_next && m == npair - 1;
+            u32x4 raw[WL::PER], rawa[AL::PER];
+            if (pf) {
+                issue_window16<C, W, NTHREADS>((const _Float16*)p.x + (long long)bn * p.batch_stride, t0n, lenn, raw);
+                issue_apron16<C, W, NTHREADS>((const _Float16*)p.x + (long long)bn * p.batch_stride, t0n, lenn, p.g1,
+                                              rawa);
             }
             if (interior) {
 #pragma unroll
@@ -565,41 +549,28 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
             MV_LAP(tr, TR_EPI);
             __syncthreads();  // Y16 complete, A16 free
             MV_LAP(tr, TR_BARRIER);
-            if constexpr (XREG) {
-                if (pf) {
-                    commit_raw16<C, W, NTHREADS>(raw, A0, RS, t0n, lenn);
-                    commit_apron16<C, W, NTHREADS>(rawa, A0, RS, t0n, lenn, p.g1);
-                }
-                MV_LAP(tr, TR_LOADX);
+            if (pf) {
+                commit_raw16<C, W, NTHREADS>(raw, A0, RS, t0n, lenn);
+                commit_apron16<C, W, NTHREADS>(rawa, A0, RS, t0n, lenn, p.g1);
             }
+            MV_LAP(tr, TR_LOADX);
             const int m_next = m + 1 < npair ? m + 1 : 0;
-            if constexpr (XREG) {
-                // x + bias + conv2(...): the K loop accumulates into the residual registers themselves
+            // x + bias + conv2(...): the K loop accumulates into the residual registers themselves
 #pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
+            for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                    for (int tn = 0; tn < TN; ++tn) X[tm][tn] += bias[tm];
-                conv_window<TM, TN>(X, Y0 + ((wn * TN * 16 + lr) - pad2) * RS + lg * 16, RS, p.K, 1, NKC,
-                                    (const u32x4*)p.w2[m] + woff, mtile_stride, &wpre);
-            } else {
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = bias[tm];
-                conv_window<TM, TN>(acc, Y0 + ((wn * TN * 16 + lr) - pad2) * RS + lg * 16, RS, p.K, 1, NKC,
-                                    (const u32x4*)p.w2[m] + woff, mtile_stride, &wpre);
-            }
+                for (int tn = 0; tn < TN; ++tn) X[tm][tn] += bias[tm];
+            conv_window<TM, TN>(X, Y0 + ((wn * TN * 16 + lr) - pad2) * RS + lg * 16, RS, p.K, 1, NKC,
+                                (const u32x4*)p.w2[m] + woff, mtile_stride, &wpre);
             MV_LAP(tr, TR_KLOOP);
             lds_bias(bias, bias_s, 2 * m_next, C, chl);
             wpre.request((const u32x4*)p.w1[m_next] + woff, mtile_stride, p.K * NKC);
-            if constexpr (XREG) {
-                if (m + 1 < npair) {
+            if (m + 1 < npair) {
 #pragma unroll
-                    for (int tn = 0; tn < TN; ++tn) {
-                        const int g = t0 + (wn * TN + tn) * 16 + lr;
-                        *(u32x4*)(A0 + frag0 + tn * FRAG_TN) =
-                            pack8_bf16_lrelu(X[0][tn], X[1][tn], 0.1f, interior || (g >= 0 && g < len));
-                    }
+                for (int tn = 0; tn < TN; ++tn) {
+                    const int g = t0 + (wn * TN + tn) * 16 + lr;
+                    *(u32x4*)(A0 + frag0 + tn * FRAG_TN) =
+                        pack8_bf16_lrelu(X[0][tn], X[1][tn], 0.1f, interior || (g >= 0 && g < len));
                 }
             }
         }
@@ -610,10 +581,8 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
             // the result leaves as float16 through the Y tile (the A tile may already hold the next window)
             __syncthreads();  // every wave is done reading Y16 as conv2's operand
             MV_LAP(tr, TR_BARRIER);
-            if constexpr (XREG) {
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn) *(u32x4*)(Y0 + frag0 + tn * FRAG_TN) = pack8_f16_sat(X[0][tn], X[1][tn]);
-            }
+            for (int tn = 0; tn < TN; ++tn) *(u32x4*)(Y0 + frag0 + tn * FRAG_TN) = pack8_f16_sat(X[0][tn], X[1][tn]);
             MV_LAP(tr, TR_EPI);
             __syncthreads();
             MV_LAP(tr, TR_BARRIER);
@@ -630,11 +599,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
                     const int g = t0 + n;
                     if (n < p.H || n >= p.H + p.NT || g >= len) continue;
                     const long long e = (long long)g * C + ch;
-                    f32x4 q;
-                    if constexpr (XREG)
-                        q = X[tm][tn];
-                    else
-                        q = acc[tm][tn] + ld4(xb, e, p.io16);
+                    f32x4 q = X[tm][tn];
                     if (p.mode == ACC_ADD) {
                         q += ld4(ob, e, p.io16);
                     } else if (p.mode == ACC_ADD_DIV) {

@@ -31,25 +31,25 @@ struct FusedCfg {
     int C, W, threads, npair;
     FusedKernel k;
     const char* name;
-    FusedKernel k16;  // float16-IO variant (XREG kernels), null if there is none
+    FusedKernel k16;  // float16-IO variant, null if there is none
     FusedKernel k16_one;  // ... specialised for one pair per launch, null if there is none
 };
-//                         C   WM WN TN  XREG
+//                         C   WM WN TN [IO16X [ONE]]
 static const FusedCfg kFused[] = {
     // 8 waves (two per SIMD): the second wave hides LDS / L2 latency and the epilogue phases
-    {32, 768, 512, 3, fused_rb_kernel<32, 1, 8, 6, true>, "fused_rb_kernel<C32,WM1,WN8,TN6,xreg>",
-     fused_rb_kernel<32, 1, 8, 6, true, true>, fused_rb_kernel<32, 1, 8, 6, true, true, true>},
-    {64, 448, 512, 3, fused_rb_kernel<64, 2, 4, 7, true>, "fused_rb_kernel<C64,WM2,WN4,TN7,xreg>",
-     fused_rb_kernel<64, 2, 4, 7, true, true>, fused_rb_kernel<64, 2, 4, 7, true, true, true>},
-    {128, 224, 512, 3, fused_rb_kernel<128, 4, 2, 7, true>, "fused_rb_kernel<C128,WM4,WN2,TN7,xreg>",
-     fused_rb_kernel<128, 4, 2, 7, true, true>, fused_rb_kernel<128, 4, 2, 7, true, true, true>},
-    {256, 112, 512, 1, fused_rb_kernel<256, 8, 1, 7, true>, "fused_rb_kernel<C256,WM8,WN1,TN7,xreg>",
-     fused_rb_kernel<256, 8, 1, 7, true, true>, fused_rb_kernel<256, 8, 1, 7, true, true, true>},
+    {32, 768, 512, 3, fused_rb_kernel<32, 1, 8, 6>, "fused_rb_kernel<C32,WM1,WN8,TN6,xreg>",
+     fused_rb_kernel<32, 1, 8, 6, true>, fused_rb_kernel<32, 1, 8, 6, true, true>},
+    {64, 448, 512, 3, fused_rb_kernel<64, 2, 4, 7>, "fused_rb_kernel<C64,WM2,WN4,TN7,xreg>",
+     fused_rb_kernel<64, 2, 4, 7, true>, fused_rb_kernel<64, 2, 4, 7, true, true>},
+    {128, 224, 512, 3, fused_rb_kernel<128, 4, 2, 7>, "fused_rb_kernel<C128,WM4,WN2,TN7,xreg>",
+     fused_rb_kernel<128, 4, 2, 7, true>, fused_rb_kernel<128, 4, 2, 7, true, true>},
+    {256, 112, 512, 1, fused_rb_kernel<256, 8, 1, 7>, "fused_rb_kernel<C256,WM8,WN1,TN7,xreg>",
+     fused_rb_kernel<256, 8, 1, 7, true>, fused_rb_kernel<256, 8, 1, 7, true, true>},
     // 4-wave variants, kept for A/B runs (MV_FUSE bit mask: 2 -> C32, 4 -> C64, 8 -> C128)
-    {32, 768, 256, 3, fused_rb_kernel<32, 1, 4, 12, true>, "fused_rb_kernel<C32,WM1,WN4,TN12,xreg>", nullptr, nullptr},
-    {64, 320, 256, 3, fused_rb_kernel<64, 2, 2, 10, true>, "fused_rb_kernel<C64,WM2,WN2,TN10,xreg>", nullptr, nullptr},
-    {128, 96, 256, 3, fused_rb_kernel<128, 4, 1, 6, true>, "fused_rb_kernel<C128,WM4,WN1,TN6,xreg>",
-     fused_rb_kernel<128, 4, 1, 6, true, true>, nullptr},
+    {32, 768, 256, 3, fused_rb_kernel<32, 1, 4, 12>, "fused_rb_kernel<C32,WM1,WN4,TN12,xreg>", nullptr, nullptr},
+    {64, 320, 256, 3, fused_rb_kernel<64, 2, 2, 10>, "fused_rb_kernel<C64,WM2,WN2,TN10,xreg>", nullptr, nullptr},
+    {128, 96, 256, 3, fused_rb_kernel<128, 4, 1, 6>, "fused_rb_kernel<C128,WM4,WN1,TN6,xreg>",
+     fused_rb_kernel<128, 4, 1, 6, true>, nullptr},
 };
 
 static int env_or(const char* name, int dflt) {

@@ -10,8 +10,8 @@ can attach the measured traffic to the dominant kernel.
 
 rocprofv3 sees one symbol for all ResBlock kernel sizes of `fused_rb_kernel<C...>`; they are told apart by the
 position of the dispatch within a step, which for HiFi-GAN V1 (resblock_kernel_sizes 3/7/11, hifigan.hip
-launch order) is fixed: C256 runs 3 + 3 + 3 pair launches, C128 one whole k=3 launch + 3 + 3, C64 three k=11
-pair launches after its stage launch.
+launch order) is fixed: C256 runs 3 + 3 + 3 single-pair launches, C128 one whole k=3 launch, then 3 + 3
+single-pair ones (a different symbol: the ONE variant), C64 three k=11 single-pair launches after its stage launch.
 """
 import collections
 import csv
@@ -19,17 +19,22 @@ import json
 import re
 import sys
 
-# launches per step of each ResBlock kernel size, in launch order
-RB_PATTERN = {256: [(3, 3), (7, 3), (11, 3)], 128: [(3, 1), (7, 3), (11, 3)], 64: [(11, 3)], 32: []}
+# launches per step of each ResBlock kernel size, in launch order, per kernel symbol: (C, single-pair variant)
+RB_PATTERN = {
+    (256, True): [(3, 3), (7, 3), (11, 3)],
+    (128, False): [(3, 1)],
+    (128, True): [(7, 3), (11, 3)],
+    (64, True): [(11, 3)],
+}
 
 
 def lib_name(rocprof_name, nth):
     """library name of the nth dispatch (0-based, in order) of a rocprof kernel symbol; None = not a fused kernel"""
-    m = re.search(r"fused_rb_kernel<(\d+), (\d+), (\d+), (\d+), (true|false)", rocprof_name)
+    m = re.search(r"fused_rb_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (true|false)>", rocprof_name)
     if m:
-        c, wm, wn, tn, xreg = m.groups()
-        base = f"fused_rb_kernel<C{c},WM{wm},WN{wn},TN{tn},{'xreg' if xreg == 'true' else 'pair'}>"
-        pat = RB_PATTERN.get(int(c)) or []
+        c, wm, wn, tn, _, one = m.groups()
+        base = f"fused_rb_kernel<C{c},WM{wm},WN{wn},TN{tn},xreg>"
+        pat = RB_PATTERN.get((int(c), one == "true")) or []
         per_step = sum(n for _, n in pat)
         if per_step:
             i = nth % per_step
