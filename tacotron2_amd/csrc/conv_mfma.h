@@ -78,6 +78,8 @@ struct ConvParams {
     float div;           // ACC_ADD_DIV divisor
     int act;             // linear epilogue: 0 = none, 1 = tanh(acc + bias) before residual / accumulate (model.py:172)
     int epi_lds;         // linear epilogue, one float16 output: leave through LDS with 16-byte coalesced stores
+    int xcd_ny;          // > 0: 1-D grid; the ny M-blocks of a row tile run back to back on ONE XCD (see conv_cl_kernel)
+    int nx;              // row tiles (xcd_ny > 0)
 };
 
 template <bool BF16>
@@ -456,7 +458,18 @@ void conv_cl_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int b = blockIdx.z;
-    const int n0 = blockIdx.x * NT;
+    // Workgroups go to the 8 XCDs round-robin by linear index, and each XCD has its own L2.  With the natural
+    // (row tile, M block) grid the M blocks of one row tile land on different XCDs and every one of them pulls the
+    // tile's activation rows from HBM / Infinity Cache again.  Remapped, XCD x runs row tiles x, x+8, ... and for each
+    // of them its ny M-blocks in consecutive slots, so the rows are fetched once per tile and re-read from that L2.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (p.xcd_ny > 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        by = slot % p.xcd_ny;
+        bx = (slot / p.xcd_ny) * 8 + xcd;
+        if (bx >= p.nx) return;
+    }
+    const int n0 = bx * NT;
     const int len = p.lengths ? p.lengths[b] : p.Tmax;
     const int n_ext = len * p.n_rows_per_frame + p.n_extra;
     if (n0 >= n_ext) return;
@@ -471,7 +484,7 @@ void conv_cl_kernel(const ConvParams p) {
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int mtile0 = blockIdx.y * (MT / 16) + wm * TM;
+    const int mtile0 = by * (MT / 16) + wm * TM;
     const long long mtile_stride = (long long)p.steps_total * 64;
     const u32x4* wlane = (const u32x4*)p.w + (long long)mtile0 * mtile_stride + lane;
 
@@ -512,7 +525,7 @@ void conv_cl_kernel(const ConvParams p) {
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm) {
                     const int ml = (wm * TM + tm) * 16 + lg * 4;
-                    const f32x4 bias = *(const f32x4*)(p.bias + blockIdx.y * MT + ml);
+                    const f32x4 bias = *(const f32x4*)(p.bias + by * MT + ml);
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn) {
                         const int nl = (wn * TN + tn) * 16 + lr;
@@ -545,7 +558,7 @@ void conv_cl_kernel(const ConvParams p) {
             }
             __syncthreads();
             // a block's M range lies on one side of the split (launch_layer checks split % MT == 0)
-            int mbase = blockIdx.y * MO;
+            int mbase = by * MO;
             const int oi = (EPI == EPI_LINEAR && mbase >= p.split) ? 1 : 0;
             if (oi) mbase -= p.split;
             const ConvOut& o = p.out[oi];

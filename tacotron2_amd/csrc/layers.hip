@@ -299,7 +299,14 @@ int launch_layer(const Layer& L, const SrcBind* srcs, int nsrc, const LaunchArgs
                 (L.epi == EPI_LINEAR || !two) && a.resid_batch_stride % 8 == 0;
     const long long n_max = (long long)a.Tmax * a.n_rows_per_frame + a.n_extra;
     if (n_max <= 0 || a.B <= 0) return MV_OK;
-    dim3 grid((unsigned)((n_max + tc.NT() - 1) / tc.NT()), (unsigned)(L.M / tc.MT()), (unsigned)a.B);
+    const unsigned nx = (unsigned)((n_max + tc.NT() - 1) / tc.NT()), ny = (unsigned)(L.M / tc.MT());
+    dim3 grid(nx, ny, (unsigned)a.B);
+    static const int xcd_on = env_int("MV_XCD_SWIZZLE", 1);
+    if (xcd_on && ny > 1) {  // M-blocks of a row tile on one XCD (conv_cl_kernel)
+        p.xcd_ny = (int)ny;
+        p.nx = (int)nx;
+        grid = dim3((nx + 7) / 8 * 8 * ny, 1, (unsigned)a.B);
+    }
     dim3 block(tc.WM * tc.WN * 64);
     ConvKernel k = pick_kernel(L.bf16, L.epi, L.cfg);
     if (prof) prof->begin(stream, layer_kernel_name(L), L.alg_macs_per_n * a.n_rows_per_frame);
