@@ -73,7 +73,7 @@ int build_layer(Layer* L, const std::vector<SrcSpec>& srcs, int M, const std::ve
     const bool big = tc.WM * tc.WN >= 8;
     const size_t lds_budget =
         (size_t)env_int(bf16 ? (big ? "MV_LDS_BUDGET_KB_BIG" : "MV_LDS_BUDGET_KB") : "MV_LDS_BUDGET_KB_FP32",
-                        bf16 && !big ? 64 : 128) * 1024;
+                        bf16 && !big ? 72 : 128) * 1024;  // 4-wave tiles: two blocks per CU (2 x 72 KB of 160)
     L->npass = 0;
     L->lds_bytes = 0;
     L->steps_total = 0;
