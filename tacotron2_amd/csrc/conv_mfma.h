@@ -48,7 +48,8 @@ struct ConvPass {
     int pad_left;            // input row of (n, tap) = n + tap*dil - pad_left
     int rows_per_frame;      // valid input rows of sequence b = lengths[b] * rows_per_frame
     float slope;             // leaky_relu slope applied while staging (1 = identity)
-    int src_f16;             // the source tensor is float16 (bf16 mode stores activations as fp16)
+    int src_f16;             // source storage: 0 float32, 1 float16 (bf16 mode's activations), 2 bfloat16 (a tensor
+                             // that is only ever an MFMA operand: staged by plain 16-byte copies, no activation)
 };
 
 struct ConvOut {
@@ -131,8 +132,12 @@ __device__ __forceinline__ f32x4 ld4(const void* base, long long e, int f16) {
     }
     return *(const f32x4*)((const float*)base + e);
 }
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi);
 __device__ __forceinline__ void st4(void* base, long long e, const f32x4& v, int f16) {
-    if (f16) {
+    if (f16 == 2) {  // bfloat16 (operand-only tensors, see ConvPass::src_f16)
+        *(unsigned long long*)((unsigned short*)base + e) =
+            ((unsigned long long)pack_bf16(v[2], v[3]) << 32) | pack_bf16(v[0], v[1]);
+    } else if (f16) {
         f16x4 h;
 #pragma unroll
         for (int i = 0; i < 4; ++i) h[i] = (_Float16)fminf(fmaxf(v[i], -65504.f), 65504.f);
@@ -146,6 +151,33 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
     bf16x2 v = {(__bf16)lo, (__bf16)hi};
     return __builtin_bit_cast(unsigned, v);
+}
+
+// The same for a bfloat16 source (ConvPass::src_f16 == 2): the tile is a plain copy, 16 bytes = 8 channels per unit.
+template <int NTHREADS>
+__device__ __forceinline__ void stage_tile_raw(char* smem, const ConvPass& cp, const void* src_b, int row0, int rows,
+                                               int len_rows, int RS) {
+    constexpr int U = 8;
+    const int upr = cp.cb / 8;
+    const int total = rows * upr;
+    for (int base = threadIdx.x; base < total; base += NTHREADS * U) {
+        u32x4 x[U];
+        int dst[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int idx = base + k * NTHREADS;
+            const int r = idx / upr;
+            const int u = idx - r * upr;
+            const int in_row = row0 + r;
+            dst[k] = idx < total ? r * RS + u * 16 : -1;
+            x[k] = u32x4{0u, 0u, 0u, 0u};
+            if (idx < total && in_row >= 0 && in_row < len_rows)
+                x[k] = *(const u32x4*)((const unsigned short*)src_b + (long long)in_row * cp.row_stride + cp.cin_off + u * 8);
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k)
+            if (dst[k] >= 0) *(u32x4*)(smem + dst[k]) = x[k];
+    }
 }
 
 // Stage rows [row0, row0+rows) x channels [cin_off, cin_off+cb) of one sequence into LDS.
@@ -497,7 +529,10 @@ void conv_cl_kernel(const ConvParams p) {
         const long long src_off = (long long)b * cp.batch_stride;
         const void* src_b = cp.src_f16 ? (const void*)((const _Float16*)cp.src + src_off)
                                        : (const void*)((const float*)cp.src + src_off);
-        stage_tile<BF16, NTHREADS>(smem, cp, src_b, n0 - cp.pad_left, rows, len * cp.rows_per_frame, RS);
+        if (BF16 && cp.src_f16 == 2)
+            stage_tile_raw<NTHREADS>(smem, cp, src_b, n0 - cp.pad_left, rows, len * cp.rows_per_frame, RS);
+        else
+            stage_tile<BF16, NTHREADS>(smem, cp, src_b, n0 - cp.pad_left, rows, len * cp.rows_per_frame, RS);
         __syncthreads();
         const int nkc = cp.cb / CH;
         const char* lds_b = smem + (wn * TN * 16 + lr) * RS + lg * 16;
@@ -531,10 +566,15 @@ void conv_cl_kernel(const ConvParams p) {
                         const int nl = (wn * TN + tn) * 16 + lr;
                         f32x4 v = acc[tm][tn] + bias;
                         if (p.act == 1) v = f32x4{tanhf(v[0]), tanhf(v[1]), tanhf(v[2]), tanhf(v[3])};
-                        f16x4 h;
+                        if (p.out[0].f16 == 2) {  // bfloat16 output (operand-only tensor): the tile holds bf16
+                            *(unsigned long long*)(smem + nl * TRS + ml * 2) =
+                                ((unsigned long long)pack_bf16(v[2], v[3]) << 32) | pack_bf16(v[0], v[1]);
+                        } else {
+                            f16x4 h;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) h[i] = (_Float16)fminf(fmaxf(v[i], -65504.f), 65504.f);
-                        *(f16x4*)(smem + nl * TRS + ml * 2) = h;
+                            for (int i = 0; i < 4; ++i) h[i] = (_Float16)fminf(fmaxf(v[i], -65504.f), 65504.f);
+                            *(f16x4*)(smem + nl * TRS + ml * 2) = h;
+                        }
                     }
                 }
             } else {
@@ -549,10 +589,18 @@ void conv_cl_kernel(const ConvParams p) {
                         const int nl = (wn * TN + tn) * 16 + lr;
                         const f32x4 t = acc[2 * tp][tn] + bt;
                         const f32x4 sg = acc[2 * tp + 1][tn] + bs;
-                        f16x4 h;
+                        f32x4 gv;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) h[j] = (_Float16)gate_act<BF16>(t[j], sg[j]);
-                        *(f16x4*)(smem + nl * TRS + cl * 2) = h;
+                        for (int j = 0; j < 4; ++j) gv[j] = gate_act<BF16>(t[j], sg[j]);
+                        if (p.out[0].f16 == 2) {
+                            *(unsigned long long*)(smem + nl * TRS + cl * 2) =
+                                ((unsigned long long)pack_bf16(gv[2], gv[3]) << 32) | pack_bf16(gv[0], gv[1]);
+                        } else {
+                            f16x4 h;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) h[j] = (_Float16)gv[j];
+                            *(f16x4*)(smem + nl * TRS + cl * 2) = h;
+                        }
                     }
                 }
             }

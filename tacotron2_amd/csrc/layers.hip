@@ -297,6 +297,19 @@ int launch_layer(const Layer& L, const SrcBind* srcs, int nsrc, const LaunchArgs
     };
     p.epi_lds = epi_lds_on && L.bf16 && unit_ok(a.out[0]) && (!two || (a.split % mo == 0 && unit_ok(a.out[1]))) &&
                 (L.epi == EPI_LINEAR || !two) && a.resid_batch_stride % 8 == 0;
+    // bfloat16 storage (dtype code 2) is for tensors that are only ever MFMA operands: a plain copy on the way in,
+    // the coalescing epilogue's raw store on the way out
+    for (int i = 0; i < L.npass; ++i) {
+        const SrcBind& sb = srcs[L.pass[i].src];
+        if (sb.f16 == 2 && !(L.bf16 && sb.slope == 1.0f)) {
+            set_error("launch_layer: a bfloat16 source needs a bf16 layer without input activation");
+            return MV_EINVAL;
+        }
+    }
+    if (a.out[0].f16 == 2 && !((p.epi_lds || !L.bf16) && !two && !a.resid && a.out[0].mode == ACC_STORE)) {
+        set_error("launch_layer: a bfloat16 output must be a plain store (single output, no residual, no accumulate)");
+        return MV_EINVAL;
+    }
     const long long n_max = (long long)a.Tmax * a.n_rows_per_frame + a.n_extra;
     if (n_max <= 0 || a.B <= 0) return MV_OK;
     const unsigned nx = (unsigned)((n_max + tc.NT() - 1) / tc.NT()), ny = (unsigned)(L.M / tc.MT());

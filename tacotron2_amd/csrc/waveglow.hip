@@ -394,6 +394,11 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
     ws += WaveglowHandle::al(bl * Cp * 4);
     static const int io16_env = env_or_int("MV_WG_IO16", 0);  // measured slower than float32 storage at B = 1 (staging converts more than it saves)
     const int io16 = h->precision == MV_PREC_BF16 && io16_env ? 1 : 0;
+    // The gated activations and the upsampled mel are read as MFMA operands only: in bf16 mode they are stored as
+    // bfloat16, rounded where they are produced instead of where they are staged -- the same values reach the
+    // MFMAs, at half the bytes and with plain 16-byte copies into LDS.
+    static const int opbf_env = env_or_int("MV_WG_OPERAND_BF16", 1);
+    const int opd = h->precision == MV_PREC_BF16 && opbf_env ? 2 : io16;
     float* AUDW = (float*)ws;
     // float output: the flow state lives directly in the caller's wav buffer
     float* AUD = out_format == MV_OUT_F32 ? (float*)wav : AUDW;
@@ -408,7 +413,7 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
         a.n_rows_per_frame = 1;
         a.n_extra = 3;
         const long long per_frame = (long long)spf * h->ncond;  // = 256 * n_mel
-        a.out[0] = ConvOut{SPECT, (long long)Tmax * per_frame, 0, per_frame, (int)per_frame, ACC_STORE, io16};
+        a.out[0] = ConvOut{SPECT, (long long)Tmax * per_frame, 0, per_frame, (int)per_frame, ACC_STORE, opd};
         if ((rc = launch_layer(h->up, &sb, 1, a, stream, prof))) return rc;
     }
     {
@@ -429,15 +434,15 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
             MV_HIP(hipGetLastError());
         }
         for (int i = 0; i < nl; ++i) {
-            SrcBind sb[2] = {{H, bsC, Cp, spf, 1.0f, io16}, {SPECT, (long long)L * h->ncond, h->ncond, spf, 1.0f, io16}};
+            SrcBind sb[2] = {{H, bsC, Cp, spf, 1.0f, io16}, {SPECT, (long long)L * h->ncond, h->ncond, spf, 1.0f, opd}};
             LaunchArgs a;
             a.lengths = lengths;
             a.B = B;
             a.Tmax = Tmax;
             a.n_rows_per_frame = spf;
-            a.out[0] = ConvOut{ACTS, bsC, 0, (long long)spf * Cp, Cp, ACC_STORE, io16};
+            a.out[0] = ConvOut{ACTS, bsC, 0, (long long)spf * Cp, Cp, ACC_STORE, opd};
             if ((rc = launch_layer(f.in_layers[i], sb, 2, a, stream, prof))) return rc;
-            SrcBind sa{ACTS, bsC, Cp, spf, 1.0f, io16};
+            SrcBind sa{ACTS, bsC, Cp, spf, 1.0f, opd};
             LaunchArgs r;
             r.lengths = lengths;
             r.B = B;
