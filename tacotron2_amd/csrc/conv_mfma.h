@@ -59,7 +59,9 @@ struct ConvOut {
     long long valid_per_frame;   // elements e with 0 <= e < lengths[b]*valid_per_frame are written
     int row_stride;              // elements per n
     int mode;                    // ACC_*
-    int f16;
+    int f16;                     // storage: 0 float32, 1 float16, 2 bfloat16 (plain stores of operand-only tensors)
+    void* copy_bf16;             // optional second copy of what is stored, as bfloat16, same indexing (the MFMA-operand
+                                 // view of a float32 residual stream)
 };
 
 struct ConvParams {
@@ -477,6 +479,7 @@ __device__ __forceinline__ void store_out(const ConvOut& o, int b, long long e, 
         v[3] = v[3] / div;
     }
     st4(o.ptr, eb, v, o.f16);
+    if (o.copy_bf16) st4(o.copy_bf16, eb, v, 2);
 }
 
 // 4-wave tiles with 64 accumulator registers fit 3 waves per SIMD (<= 168 VGPRs; the allocator lands just above
@@ -668,6 +671,10 @@ void conv_cl_kernel(const ConvParams p) {
                         *(f32x4*)((float*)o.ptr + eb) = y[0];
                         *(f32x4*)((float*)o.ptr + eb + 4) = y[1];
                     }
+                    if (o.copy_bf16)
+                        *(u32x4*)((unsigned short*)o.copy_bf16 + eb) =
+                            u32x4{pack_bf16(y[0][0], y[0][1]), pack_bf16(y[0][2], y[0][3]), pack_bf16(y[1][0], y[1][1]),
+                                  pack_bf16(y[1][2], y[1][3])};
                 }
             }
             return;

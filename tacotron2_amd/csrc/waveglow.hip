@@ -68,7 +68,8 @@ __global__ __launch_bounds__(256) void wg_noise_kernel(const float* __restrict__
 // glow.py:155: H = start(audio_0) (1x1, n_half -> C)
 __global__ __launch_bounds__(256) void wg_start_kernel(const float* __restrict__ aud, int ng, int off, int n_half,
                                                        const float* __restrict__ w, const float* __restrict__ bias,
-                                                       int C, int Cp, long long rows, void* __restrict__ H, int h16) {
+                                                       int C, int Cp, long long rows, void* __restrict__ H, int h16,
+                                                       unsigned short* __restrict__ Hb) {
     const int q = Cp / 4;  // float4 units per row
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= rows * q) return;
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(256) void wg_start_kernel(const float* __restrict__
         }
     }
     st4(H, r * Cp + c0, v, h16);
+    if (Hb) st4(Hb, r * Cp + c0, v, 2);  // the MFMA-operand view of H (see waveglow_infer)
 }
 
 // glow.py:175 (end), 280-285 (coupling inverse, W^-1), 287-292 (early noise).  One wave per 16 steps:
@@ -399,6 +401,9 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
     // MFMAs, at half the bytes and with plain 16-byte copies into LDS.
     static const int opbf_env = env_or_int("MV_WG_OPERAND_BF16", 1);
     const int opd = h->precision == MV_PREC_BF16 && opbf_env ? 2 : io16;
+    // Likewise the residual stream H: it accumulates in float32, and every kernel that updates it also leaves a
+    // bfloat16 copy (in the unused half of the ACTS buffer) for the next gated conv to stage by plain copies.
+    unsigned short* Hb = opd == 2 ? (unsigned short*)((char*)ACTS + WaveglowHandle::al(bl * Cp * 2)) : nullptr;
     float* AUDW = (float*)ws;
     // float output: the flow state lives directly in the caller's wav buffer
     float* AUD = out_format == MV_OUT_F32 ? (float*)wav : AUDW;
@@ -430,11 +435,11 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
             const long long rows = (long long)B * L;
             const long long total = rows * (Cp / 4);
             hipLaunchKernelGGL(wg_start_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, AUD, ng,
-                               ng - f.Ck, f.n_half, f.start_w, f.start_b, h->C, Cp, rows, H, io16);
+                               ng - f.Ck, f.n_half, f.start_w, f.start_b, h->C, Cp, rows, H, io16, Hb);
             MV_HIP(hipGetLastError());
         }
         for (int i = 0; i < nl; ++i) {
-            SrcBind sb[2] = {{H, bsC, Cp, spf, 1.0f, io16}, {SPECT, (long long)L * h->ncond, h->ncond, spf, 1.0f, opd}};
+            SrcBind sb[2] = {Hb ? SrcBind{Hb, bsC, Cp, spf, 1.0f, 2} : SrcBind{H, bsC, Cp, spf, 1.0f, io16}, {SPECT, (long long)L * h->ncond, h->ncond, spf, 1.0f, opd}};
             LaunchArgs a;
             a.lengths = lengths;
             a.B = B;
@@ -451,7 +456,7 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
             const int skip_mode = i == 0 ? ACC_STORE : ACC_ADD;
             if (i < nl - 1) {
                 r.split = h->C;
-                r.out[0] = ConvOut{H, bsC, 0, (long long)spf * Cp, Cp, ACC_ADD, io16};
+                r.out[0] = ConvOut{H, bsC, 0, (long long)spf * Cp, Cp, ACC_ADD, io16, Hb};
                 r.out[1] = ConvOut{SKIP, bsC, 0, (long long)spf * Cp, Cp, skip_mode, io16};
             } else {
                 r.out[0] = ConvOut{SKIP, bsC, 0, (long long)spf * Cp, Cp, skip_mode, io16};
