@@ -28,11 +28,17 @@ struct WgFlow {
     float* end_b = nullptr;    // device [2*n_half]
     float* winv = nullptr;     // device [Ck][Ck]
     std::vector<Layer> in_layers, res_skip;
+    // bf16 mode ("folded skip path", see waveglow_build): the residual half of res_skip alone, and end o skip_i as one
+    // [2*n_half][Cp] matrix per layer
+    std::vector<Layer> res_only;
+    std::vector<float*> fold_w;  // device, per layer
+    float* fold_b = nullptr;     // device [2*n_half]: end.bias + end.weight * (sum of the skip biases)
 };
 
 struct WaveglowHandle : mv_handle_s {
     mv_waveglow_cfg cfg;
     int C = 0, Cp = 0, ncond = 0, melp = 0, n_rem = 0;
+    bool fold = false;  // folded skip path (WgFlow)
     Layer up;
     std::vector<WgFlow> flows;
     double macs = 0;
@@ -42,6 +48,10 @@ struct WaveglowHandle : mv_handle_s {
         for (auto& f : flows) {
             for (auto& l : f.in_layers) free_layer(&l);
             for (auto& l : f.res_skip) free_layer(&l);
+            for (auto& l : f.res_only) free_layer(&l);
+            for (float* p : f.fold_w)
+                if (p) (void)hipFree(p);
+            if (f.fold_b) (void)hipFree(f.fold_b);
             for (float* p : {f.start_w, f.start_b, f.end_w, f.end_b, f.winv})
                 if (p) (void)hipFree(p);
         }
@@ -91,6 +101,60 @@ __global__ __launch_bounds__(256) void wg_start_kernel(const float* __restrict__
     if (Hb) st4(Hb, r * Cp + c0, v, 2);  // the MFMA-operand view of H (see waveglow_infer)
 }
 
+// Folded skip path: end(sum_i skip_i(acts_i)) = sum_i (W_end W_skip_i) acts_i + const, so layer i adds
+// out8[row][j] (+)= sum_c fold_w[j][c] * acts[row][c] (2*n_half <= 8 outputs per row) instead of a 512-channel skip
+// tensor that is read-modify-written by every layer and only ever seen by the end conv.  16 lanes per row, each
+// lane 16-byte units lane + 16q of the row; the 16 partial sums meet in four shuffles.
+__global__ __launch_bounds__(256) void wg_skipfold_kernel(const void* __restrict__ acts, int acts_dt, int Cp,
+                                                          const float* __restrict__ fold_w, int nout, long long rows,
+                                                          float* __restrict__ out8, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ws = (float*)smem;  // [nout][Cp]
+    for (int i = threadIdx.x; i < nout * Cp; i += 256) ws[i] = fold_w[i];
+    __syncthreads();
+    const int l16 = threadIdx.x & 15;
+    const long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool live = row < rows;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    if (live) {
+        for (int u = l16; u < Cp / 8; u += 16) {
+            f32x4 a, b;
+            if (acts_dt == 2) {
+                const u32x4 raw = *(const u32x4*)((const unsigned short*)acts + row * Cp + u * 8);
+                a = f32x4{__uint_as_float(raw[0] << 16), __uint_as_float(raw[0] & 0xffff0000u),
+                          __uint_as_float(raw[1] << 16), __uint_as_float(raw[1] & 0xffff0000u)};
+                b = f32x4{__uint_as_float(raw[2] << 16), __uint_as_float(raw[2] & 0xffff0000u),
+                          __uint_as_float(raw[3] << 16), __uint_as_float(raw[3] & 0xffff0000u)};
+            } else {
+                a = ld4(acts, row * Cp + u * 8, acts_dt);
+                b = ld4(acts, row * Cp + u * 8 + 4, acts_dt);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (j < nout) {
+                    const f32x4 q0 = *(const f32x4*)(ws + j * Cp + u * 8), q1 = *(const f32x4*)(ws + j * Cp + u * 8 + 4);
+                    acc[j] += a[0] * q0[0] + a[1] * q0[1] + a[2] * q0[2] + a[3] * q0[3] + b[0] * q1[0] + b[1] * q1[1] +
+                              b[2] * q1[2] + b[3] * q1[3];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) acc[j] += __shfl_xor(acc[j], o);
+    }
+    if (!live || l16 >= nout) return;
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (j == l16) v = acc[j];
+    float* o = out8 + row * 8 + l16;
+    *o = accumulate ? *o + v : v;
+}
+
 // glow.py:175 (end), 280-285 (coupling inverse, W^-1), 287-292 (early noise).  One wave per 16 steps:
 // lane = 16*part + step; the 4 parts split the channels of SKIP and are summed with two shuffles.
 __global__ __launch_bounds__(256) void wg_tail_kernel(const void* __restrict__ skip, int skip16, int Cp, const float* __restrict__ end_w,
@@ -98,11 +162,12 @@ __global__ __launch_bounds__(256) void wg_tail_kernel(const void* __restrict__ s
                                                       const float* __restrict__ winv, float* __restrict__ aud, int ng,
                                                       const int32_t* __restrict__ lengths, int Tmax, int L,
                                                       int steps_per_frame, const float* __restrict__ noise, int n_early,
-                                                      float sigma) {
+                                                      float sigma, const float* __restrict__ folded) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* ws = (float*)smem;  // [2*n_half][Cp]
     const int nout = 2 * n_half;
-    for (int i = threadIdx.x; i < nout * Cp; i += 256) ws[i] = end_w[i];
+    if (!folded)
+        for (int i = threadIdx.x; i < nout * Cp; i += 256) ws[i] = end_w[i];
     __syncthreads();
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -114,7 +179,13 @@ __global__ __launch_bounds__(256) void wg_tail_kernel(const void* __restrict__ s
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    if (valid) {
+    if (valid && folded) {  // the end conv's outputs arrive ready-made (wg_skipfold_kernel); end_b = the folded bias
+        if (part == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < nout) acc[j] = folded[((long long)b * L + l) * 8 + j];
+        }
+    } else if (valid) {
         const long long se = ((long long)b * L + l) * Cp;
         for (int c4 = part; c4 < Cp / 4; c4 += 4) {
             const f32x4 v = ld4(skip, se + c4 * 4, skip16);
@@ -291,6 +362,19 @@ static int waveglow_build(WaveglowHandle* h, WeightMap& W) {
 
         f.in_layers.resize(nl);
         f.res_skip.resize(nl);
+        // Folded skip path (bf16 mode, MV_WG_FOLD): the skip halves of the res_skip layers feed nothing but the end
+        // conv, and end(sum_i skip_i) is linear, so layer i contributes (W_end W_skip_i) acts_i -- a [2*n_half][C]
+        // matrix applied on the VALU in fp32 -- and the MFMA layer keeps its residual half only.  Halves the res_skip
+        // FLOPs and drops the skip tensor's read-modify-write; the values differ from the reference order of
+        // operations by fp32 rounding only (the products are formed in double here).
+        const bool fold = bf16 && env_or_int("MV_WG_FOLD", 1) != 0;
+        h->fold = fold;
+        std::vector<double> fold_bias(2 * n_half, 0.0);
+        if (fold) {
+            f.res_only.resize(nl);
+            f.fold_w.assign(nl, nullptr);
+            for (int j = 0; j < 2 * n_half; ++j) fold_bias[j] = eb->data[j];
+        }
         for (int i = 0; i < nl; ++i) {
             snprintf(name, sizeof name, "WN.%d.in_layers.%d.weight", k, i);
             const HostTensor* iw = W.get(name);
@@ -345,11 +429,39 @@ static int waveglow_build(WaveglowHandle* h, WeightMap& W) {
             sa.pad_left = 0;
             sa.w = [=](int m, int, int ci) -> float { return ci < C ? rwd[(size_t)m * C + ci] : 0.f; };
             const int rwide = bf16 && rsC % 256 == 0 ? env_or_int("MV_WG_CFG", 1) : -1;
-            if ((rc = build_layer(&f.res_skip[i], {sa}, rsC, rb->data, bf16, EPI_LINEAR, rwide))) return rc;
-            f.res_skip[i].alg_macs_per_n = (double)rsC * C;
+            if (!fold) {
+                if ((rc = build_layer(&f.res_skip[i], {sa}, rsC, rb->data, bf16, EPI_LINEAR, rwide))) return rc;
+                f.res_skip[i].alg_macs_per_n = (double)rsC * C;
+            } else {
+                const int s0 = rsC - C;  // first skip row of res_skip_layers[i]
+                std::vector<float> fw((size_t)2 * n_half * h->Cp, 0.f);
+                for (int j = 0; j < 2 * n_half; ++j) {
+                    const float* ej = ew->data.data() + (size_t)j * C;
+                    for (int cc = 0; cc < C; ++cc) {
+                        double acc = 0;
+                        for (int m = 0; m < C; ++m) acc += (double)ej[m] * rwd[(size_t)(s0 + m) * C + cc];
+                        fw[(size_t)j * h->Cp + cc] = (float)acc;
+                    }
+                    for (int m = 0; m < C; ++m) fold_bias[j] += (double)ej[m] * rb->data[s0 + m];
+                }
+                if ((rc = upload(fw, &f.fold_w[i]))) return rc;
+                if (i < nl - 1) {
+                    std::vector<float> rbias(rb->data.begin(), rb->data.begin() + C);
+                    const int cfg = C % 256 == 0 ? env_or_int("MV_WG_RES_CFG", 0) : -1;
+                    if ((rc = build_layer(&f.res_only[i], {sa}, C, rbias, true, EPI_LINEAR, cfg))) return rc;
+                    f.res_only[i].alg_macs_per_n = (double)C * C;
+                }
+            }
         }
+        if (fold) {
+            std::vector<float> fb(fold_bias.begin(), fold_bias.end());
+            if ((rc = upload(fb, &f.fold_b))) return rc;
+        }
+        // (executed work: with the folded skip path the res_skip layers cost C*C (+ 2*n_half*C on the VALU) per layer)
         macs_step += (double)n_half * C + (double)h->ncond * 2 * C * nl + (double)nl * 2 * C * C * ks +
-                     ((double)(nl - 1) * 2 * C * C + (double)C * C) + (double)C * 2 * n_half + (double)n_rem * n_rem;
+                     (fold ? (double)(nl - 1) * C * C + (double)nl * 2 * n_half * C
+                           : (double)(nl - 1) * 2 * C * C + (double)C * C + (double)C * 2 * n_half) +
+                     (double)n_rem * n_rem;
     }
     h->n_rem = n_rem;
     h->macs = macs_step * (256 / ng) + (double)nm * nm * 1024;
@@ -448,6 +560,27 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
             a.out[0] = ConvOut{ACTS, bsC, 0, (long long)spf * Cp, Cp, ACC_STORE, opd};
             if ((rc = launch_layer(f.in_layers[i], sb, 2, a, stream, prof))) return rc;
             SrcBind sa{ACTS, bsC, Cp, spf, 1.0f, opd};
+            if (h->fold) {
+                const int nout = 2 * f.n_half;
+                const long long rows = (long long)B * L;
+                // (rows past a sequence's end hold stale activations: their sums are never read, wg_tail masks them)
+                if (prof) prof->begin(stream, "wg_skipfold_kernel", (double)nout * h->C * spf);
+                hipLaunchKernelGGL(wg_skipfold_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256),
+                                   (size_t)nout * Cp * 4, stream, (const void*)ACTS, opd, Cp, f.fold_w[i], nout, rows,
+                                   (float*)SKIP, i == 0 ? 0 : 1);
+                if (prof) prof->end(stream);
+                MV_HIP(hipGetLastError());
+                if (i < nl - 1) {
+                    LaunchArgs r;
+                    r.lengths = lengths;
+                    r.B = B;
+                    r.Tmax = Tmax;
+                    r.n_rows_per_frame = spf;
+                    r.out[0] = ConvOut{H, bsC, 0, (long long)spf * Cp, Cp, ACC_ADD, io16, Hb};
+                    if ((rc = launch_layer(f.res_only[i], &sa, 1, r, stream, prof))) return rc;
+                }
+                continue;
+            }
             LaunchArgs r;
             r.lengths = lengths;
             r.B = B;
@@ -467,9 +600,10 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
         {
             dim3 grid((L + 63) / 64, B);
             const size_t lds = (size_t)2 * f.n_half * Cp * 4;
-            hipLaunchKernelGGL(wg_tail_kernel, grid, dim3(256), lds, stream, (const void*)SKIP, io16, Cp, f.end_w, f.end_b, f.n_half, f.Ck,
-                               f.winv, AUD, ng, lengths, Tmax, L, spf, early ? noise[ni] : nullptr,
-                               early ? c.n_early_size : 0, sigma);
+            hipLaunchKernelGGL(wg_tail_kernel, grid, dim3(256), lds, stream, (const void*)SKIP, io16, Cp, f.end_w,
+                               h->fold ? f.fold_b : f.end_b, f.n_half, f.Ck, f.winv, AUD, ng, lengths, Tmax, L, spf,
+                               early ? noise[ni] : nullptr, early ? c.n_early_size : 0, sigma,
+                               h->fold ? (const float*)SKIP : nullptr);
             MV_HIP(hipGetLastError());
         }
         if (early) ++ni;
