@@ -76,11 +76,46 @@ __global__ __launch_bounds__(256) void wg_noise_kernel(const float* __restrict__
 }
 
 // glow.py:155: H = start(audio_0) (1x1, n_half -> C)
+constexpr int kStartRowsPerThread = 8;
 __global__ __launch_bounds__(256) void wg_start_kernel(const float* __restrict__ aud, int ng, int off, int n_half,
                                                        const float* __restrict__ w, const float* __restrict__ bias,
                                                        int C, int Cp, long long rows, void* __restrict__ H, int h16,
                                                        unsigned short* __restrict__ Hb) {
-    const int q = Cp / 4;  // float4 units per row
+    // a thread owns 4 channels (its weights and bias stay in registers) and walks the block's rows
+    const int q = Cp / 4;  // float4 units per row; the host launches with 256 % q == 0
+    const int c0 = (int)(threadIdx.x % q) * 4;
+    float wr[4][4], br[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + i;
+        br[i] = c < C ? bias[c] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wr[i][j] = (c < C && j < n_half) ? w[c * n_half + j] : 0.f;
+    }
+    const int rpb = 256 / q * kStartRowsPerThread;  // rows per block
+    for (int it = 0; it < kStartRowsPerThread; ++it) {
+        const long long r = (long long)blockIdx.x * rpb + it * (256 / q) + threadIdx.x / q;
+        if (r >= rows) return;
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < n_half) a[j] = aud[r * ng + off + j];
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            v[i] = (wr[i][0] * a[0] + wr[i][1] * a[1] + wr[i][2] * a[2] + wr[i][3] * a[3]) + br[i];
+        st4(H, r * Cp + c0, v, h16);
+        if (Hb) st4(Hb, r * Cp + c0, v, 2);  // the MFMA-operand view of H (see waveglow_infer)
+    }
+}
+
+// generic shapes (Cp / 4 does not divide 256, or n_half > 4)
+__global__ __launch_bounds__(256) void wg_start_generic_kernel(const float* __restrict__ aud, int ng, int off, int n_half,
+                                                               const float* __restrict__ w,
+                                                               const float* __restrict__ bias, int C, int Cp,
+                                                               long long rows, void* __restrict__ H, int h16,
+                                                               unsigned short* __restrict__ Hb) {
+    const int q = Cp / 4;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= rows * q) return;
     const long long r = idx / q;
@@ -545,9 +580,16 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
         const WgFlow& f = h->flows[k];
         {
             const long long rows = (long long)B * L;
-            const long long total = rows * (Cp / 4);
-            hipLaunchKernelGGL(wg_start_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, AUD, ng,
-                               ng - f.Ck, f.n_half, f.start_w, f.start_b, h->C, Cp, rows, H, io16, Hb);
+            const int q = Cp / 4;
+            if (q <= 256 && 256 % q == 0 && f.n_half <= 4) {
+                const long long rpb = 256 / q * kStartRowsPerThread;
+                hipLaunchKernelGGL(wg_start_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, stream, AUD,
+                                   ng, ng - f.Ck, f.n_half, f.start_w, f.start_b, h->C, Cp, rows, H, io16, Hb);
+            } else {
+                const long long total = rows * q;
+                hipLaunchKernelGGL(wg_start_generic_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                                   AUD, ng, ng - f.Ck, f.n_half, f.start_w, f.start_b, h->C, Cp, rows, H, io16, Hb);
+            }
             MV_HIP(hipGetLastError());
         }
         for (int i = 0; i < nl; ++i) {
