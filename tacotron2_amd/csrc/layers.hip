@@ -314,8 +314,17 @@ int launch_layer(const Layer& L, const SrcBind* srcs, int nsrc, const LaunchArgs
     if (n_max <= 0 || a.B <= 0) return MV_OK;
     const unsigned nx = (unsigned)((n_max + tc.NT() - 1) / tc.NT()), ny = (unsigned)(L.M / tc.MT());
     dim3 grid(nx, ny, (unsigned)a.B);
+    // M-blocks of a row tile on one XCD (conv_cl_kernel) -- when the activations are the big operand.  The price is
+    // that every XCD's L2 then cycles through all ny weight slices instead of sitting on one, so layers with few
+    // rows and many output channels (conv_pre, the first upsampler) keep the natural order.  MV_XCD_SWIZZLE:
+    // 0 never, 1 by this estimate, 2 always.
     static const int xcd_on = env_int("MV_XCD_SWIZZLE", 1);
-    if (xcd_on && ny > 1) {  // M-blocks of a row tile on one XCD (conv_cl_kernel)
+    double act_row_bytes = 0;
+    for (int i = 0; i < L.npass; ++i)
+        if (L.pass[i].tap0 == 0) act_row_bytes += (double)L.pass[i].cb * (L.bf16 ? 2 : 4);
+    const double act_bytes = (double)a.B * (double)n_max * act_row_bytes;
+    const double w_bytes = (double)L.M * L.steps_total * (L.bf16 ? 64 : 64);  // 16 rows x 1 KiB per (M tile, K step)
+    if (ny > 1 && (xcd_on == 2 || (xcd_on == 1 && act_bytes >= 8.0 * w_bytes))) {
         p.xcd_ny = (int)ny;
         p.nx = (int)nx;
         grid = dim3((nx + 7) / 8 * 8 * ny, 1, (unsigned)a.B);
