@@ -287,6 +287,9 @@ __device__ __forceinline__ void commit_apron16(const u32x4 (&raw)[ApronLoad<C, N
 // Persistent blocks walk the list of (sequence, window) pairs that actually exist: cum[b] = number of
 // windows of the sequences before b (window = NT output rows), built once per block by wave 0.
 constexpr int kMaxSeq = 1024;
+#ifndef MV_XCD_WINDOWS
+#define MV_XCD_WINDOWS 1
+#endif
 
 __device__ __forceinline__ int window_table(int* cum, const int32_t* lengths, int B, int Tmax, int rpf, int NT) {
     if (threadIdx.x < 64) {
@@ -311,6 +314,25 @@ __device__ __forceinline__ int window_table(int* cum, const int32_t* lengths, in
     __syncthreads();
     return cum[B];
 }
+
+// Which windows a persistent block walks: v0, v0 + step, ... < vend.  Workgroups go to the 8 XCDs round-robin by
+// index and every XCD has its own L2, so XCD x takes the x-th eighth of the window list and its blocks sweep it
+// side by side: neighbouring windows (which share their apron / halo rows) then meet in one L2 instead of two.
+struct WindowWalk {
+    int v0, step, vend;
+    __device__ __forceinline__ WindowWalk(int V) {
+        if ((gridDim.x & 7) == 0 && MV_XCD_WINDOWS) {
+            const int per = (V + 7) >> 3, x = blockIdx.x & 7;
+            v0 = x * per + (int)(blockIdx.x >> 3);
+            step = (int)(gridDim.x >> 3);
+            vend = (x + 1) * per < V ? (x + 1) * per : V;
+        } else {
+            v0 = blockIdx.x;
+            step = gridDim.x;
+            vend = V;
+        }
+    }
+};
 
 // largest b with cum[b] <= v  (v < cum[B])
 __device__ __forceinline__ int find_seq(const int* cum, int B, int v) {
@@ -386,10 +408,11 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int cum_s[kMaxSeq + 1];
 
-    // ---- persistent block: windows v = blockIdx.x, + gridDim.x, ... of the V that exist
+    // ---- persistent block: walks its share of the V windows that exist (WindowWalk)
     const int V = window_table(cum_s, p.lengths, p.B, p.Tmax, p.rows_per_frame, p.NT);
-    int v = blockIdx.x;
-    if (v >= V) return;
+    const WindowWalk walk(V);
+    int v = walk.v0;
+    if (v >= walk.vend) return;
     MV_TRACER(tr);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -498,8 +521,8 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
         MV_LAP(tr, TR_BARRIER);
 
         // the window after this one (its rows are requested while this one is still being computed)
-        const int vn = v + (int)gridDim.x;
-        const bool has_next = vn < V;
+        const int vn = v + walk.step;
+        const bool has_next = vn < walk.vend;
         int bn = 0, lenn = 0, t0n = 0;
         if (has_next) {
             bn = find_seq(cum_s, p.B, vn);
@@ -685,8 +708,9 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
     // persistent block over the windows that exist (the host zero-fills the waveform beforehand: rows past a
     // sequence's end are defined to be zero and no block visits them)
     const int V = window_table(cum_s, p.lengths, p.B, p.Tmax, p.rows_per_frame, p.NT);
-    int v = blockIdx.x;
-    if (v >= V) return;
+    const WindowWalk walk(V);
+    int v = walk.v0;
+    if (v >= walk.vend) return;
     const long long Lmax = (long long)p.Tmax * p.rows_per_frame;
     MV_TRACER(tr);
 
@@ -758,8 +782,8 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
         const bool interior = t0 >= 0 && t0 + W <= len;
         const void* xb = IO16 ? (const void*)((const _Float16*)p.x + (long long)b * p.batch_stride)
                                 : (const void*)((const float*)p.x + (long long)b * p.batch_stride);
-        const int vn = v + (int)gridDim.x;
-        const bool has_next = vn < V;
+        const int vn = v + walk.step;
+        const bool has_next = vn < walk.vend;
         int bn = 0, lenn = 0, out0n = 0;
         if (has_next) {
             bn = find_seq(cum_s, p.B, vn);
@@ -785,7 +809,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
                     *(u32x4*)(A0 + frag0 + tn * FRAG_TN) = pack8_bf16(lrelu4(X[0][tn], 0.1f), lrelu4(X[1][tn], 0.1f));
                 }
             } else {
-                if (j > 0 || v != (int)blockIdx.x) __syncthreads();  // every wave is done with the tiles
+                if (j > 0 || v != walk.v0) __syncthreads();  // every wave is done with the tiles
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) {
                     const int n = (wn * TN + tn) * 16 + lr;
