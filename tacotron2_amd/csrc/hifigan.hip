@@ -1,8 +1,9 @@
-// hifigan.hip -- HiFi-GAN generator (hifigan/models.py:112-174 of the reference) on conv_cl_kernel.
+// hifigan.hip -- HiFi-GAN generator (hifigan/models.py:112-174 of the reference).
 //
-// Data in HBM: every activation is float32, channels-last [B][rows][Cp] (Cp = channels rounded up
-// to 32, padding channels are exact zeros because their weights and biases are zero).
-// Launch sequence per forward (config_v1: 1 + 1 + 4*(1 + 3*3*2) + 1 = 79 launches):
+// Data in HBM: channels-last [B][rows][Cp] (Cp = channels rounded up to 32, padding channels are exact zeros
+// because their weights and biases are zero); float32 in fp32 mode, float16 between kernels in bf16 mode.
+//
+// fp32 mode, and the fallback of bf16 mode: one conv_cl_kernel launch per conv (config_v1: 79 launches) --
 //   to_channels_last  mel [B][80][T] -> [B][T][96]
 //   conv_pre          models.py:150
 //   per stage i:      ups[i] as a polyphase conv with the leaky_relu(0.1) of models.py:152 applied
@@ -12,6 +13,14 @@
 //                           the MRF mean (models.py:154-160) into ACC (store / add / add-then-divide,
 //                           the reference's own order of operations)
 //   conv_post         lrelu(0.01) -> Conv1d(C,1,7) -> tanh   (models.py:161-163), fp32 VALU
+//
+// bf16 mode: the ResBlocks run in the persistent fused kernels of fused_rb.h (config_v1: 27 launches) --
+//   C256, C128:  (conv, conv) pairs one launch each (launch_fused_rb), a whole k = 3 ResBlock where its halo leaves
+//                >= 80 % of the window
+//   C64:         one stage launch for the k = 3 and k = 7 ResBlocks (launch_fused_stage), k = 11 pair by pair
+//   C32:         one stage launch for all three ResBlocks + the MRF mean + conv_post
+// with the weights of those layers packed a second time in the pair-interleaved channel order the fused kernels
+// use (RbPair::c1p / c2p).
 #include <cmath>
 
 #include "fused_rb.h"

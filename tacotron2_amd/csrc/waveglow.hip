@@ -1,7 +1,6 @@
 // waveglow.hip -- WaveGlow.infer (waveglow/glow.py:251-295 of the reference) on conv_cl_kernel.
 //
-// Data in HBM (channels-last, L = 256*T/n_group time steps per sequence; float32, except that in bf16 mode
-// SPECT, H, SKIP and ACTS can be stored as float16 with MV_WG_IO16=1):
+// Data in HBM (channels-last, L = 256*T/n_group time steps per sequence):
 //   SPECT [B][L][n_mel*n_group]  upsampled + regrouped mel (glow.py:252-260); the transposed conv
 //                                is a 4-tap polyphase conv whose M order is permuted so that its
 //                                natural output [frame][phase*80+mel] IS [l][mel*n_group+g]
@@ -10,10 +9,14 @@
 //                                just lowers the start.  After flow 0 this buffer is the waveform
 //                                (sample = l*n_group + c, glow.py:294).
 //   H, SKIP, ACTS [B][L][C]      WN state (glow.py:153-175)
-// Per flow: start (VALU) -> n_layers x { in_layer + cond slice + gate (MFMA, EPI_GATE),
-// res_skip (MFMA, split epilogue: H += res, SKIP += skip) } -> tail (VALU: end 1x1, affine
-// coupling inverse, W^-1 1x1, early-output noise).  The cond_layer (glow.py:159) is never
-// materialised: each layer's 2C-slice of it is a second 1-tap input of that layer's GEMM.
+// fp32 mode: everything float32.  Per flow: start (VALU) -> n_layers x { in_layer + cond slice + gate (MFMA,
+// EPI_GATE), res_skip (MFMA, split epilogue: H += res, SKIP += skip) } -> tail (VALU: end 1x1, affine coupling
+// inverse, W^-1 1x1, early-output noise).  The cond_layer (glow.py:159) is never materialised: each layer's
+// 2C-slice of it is a second 1-tap input of that layer's GEMM.
+// bf16 mode: tensors that are only ever MFMA operands (SPECT, ACTS, and a copy Hb of the float32 residual stream H
+// kept by the kernels that update it) are stored as bfloat16 and staged by plain copies; the skip halves of the
+// res_skip layers are folded with the end conv into one [2*n_half][C] matrix per layer (wg_skipfold_kernel, fp32
+// VALU), so the MFMA layer keeps its residual half and there is no skip tensor: see waveglow_build.
 #include <cmath>
 
 #include "handle.h"
