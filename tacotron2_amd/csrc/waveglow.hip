@@ -34,7 +34,7 @@ struct WgFlow {
     // bf16 mode ("folded skip path", see waveglow_build): the residual half of res_skip alone, and end o skip_i as one
     // [2*n_half][Cp] matrix per layer
     std::vector<Layer> res_only;
-    std::vector<float*> fold_w;  // device, per layer
+    float* fold_w = nullptr;     // device [n_layers][2*n_half][Cp]
     float* fold_b = nullptr;     // device [2*n_half]: end.bias + end.weight * (sum of the skip biases)
 };
 
@@ -52,8 +52,7 @@ struct WaveglowHandle : mv_handle_s {
             for (auto& l : f.in_layers) free_layer(&l);
             for (auto& l : f.res_skip) free_layer(&l);
             for (auto& l : f.res_only) free_layer(&l);
-            for (float* p : f.fold_w)
-                if (p) (void)hipFree(p);
+            if (f.fold_w) (void)hipFree(f.fold_w);
             if (f.fold_b) (void)hipFree(f.fold_b);
             for (float* p : {f.start_w, f.start_b, f.end_w, f.end_b, f.winv})
                 if (p) (void)hipFree(p);
@@ -65,7 +64,10 @@ struct WaveglowHandle : mv_handle_s {
     size_t workspace_bytes(int B, int Tmax) const override {
         const size_t L = (size_t)Tmax * 256 / cfg.n_group;
         const size_t bl = (size_t)B * L;
-        return al((size_t)B * Tmax * melp * 4) + al(bl * ncond * 4) + 3 * al(bl * Cp * 4) + al(bl * cfg.n_group * 4);
+        // (folded skip path: every layer's gated activations of a flow are kept, as bfloat16, for the one fold launch
+        // at its end -- n_layers - 1 slots beyond the ACTS buffer)
+        return al((size_t)B * Tmax * melp * 4) + al(bl * ncond * 4) + 3 * al(bl * Cp * 4) + al(bl * cfg.n_group * 4) +
+               (fold ? (size_t)(cfg.n_layers - 1) * al(bl * Cp * 2) : 0);
     }
 };
 
@@ -143,38 +145,48 @@ __global__ __launch_bounds__(256) void wg_start_generic_kernel(const float* __re
 // out8[row][j] (+)= sum_c fold_w[j][c] * acts[row][c] (2*n_half <= 8 outputs per row) instead of a 512-channel skip
 // tensor that is read-modify-written by every layer and only ever seen by the end conv.  16 lanes per row, each
 // lane 16-byte units lane + 16q of the row; the 16 partial sums meet in four shuffles.
-__global__ __launch_bounds__(256) void wg_skipfold_kernel(const void* __restrict__ acts, int acts_dt, int Cp,
+__global__ __launch_bounds__(256) void wg_skipfold_kernel(const void* __restrict__ acts0,
+                                                          const void* __restrict__ acts_rest, long long slot_elems,
+                                                          int nlayers, int acts_dt, int Cp,
                                                           const float* __restrict__ fold_w, int nout, long long rows,
                                                           float* __restrict__ out8, int accumulate) {
+    // layer i reads acts0 (i = 0) or acts_rest + (i-1)*slot_elems and the i-th [nout][Cp] matrix of fold_w: with
+    // every layer's activations kept (bf16 mode), one launch per flow does the work of n_layers
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* ws = (float*)smem;  // [nout][Cp]
-    for (int i = threadIdx.x; i < nout * Cp; i += 256) ws[i] = fold_w[i];
-    __syncthreads();
     const int l16 = threadIdx.x & 15;
     const long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
     const bool live = row < rows;
+    const int esz = acts_dt == 0 ? 4 : 2;
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    if (live) {
-        for (int u = l16; u < Cp / 8; u += 16) {
-            f32x4 a, b;
-            if (acts_dt == 2) {
-                const u32x4 raw = *(const u32x4*)((const unsigned short*)acts + row * Cp + u * 8);
-                a = f32x4{__uint_as_float(raw[0] << 16), __uint_as_float(raw[0] & 0xffff0000u),
-                          __uint_as_float(raw[1] << 16), __uint_as_float(raw[1] & 0xffff0000u)};
-                b = f32x4{__uint_as_float(raw[2] << 16), __uint_as_float(raw[2] & 0xffff0000u),
-                          __uint_as_float(raw[3] << 16), __uint_as_float(raw[3] & 0xffff0000u)};
-            } else {
-                a = ld4(acts, row * Cp + u * 8, acts_dt);
-                b = ld4(acts, row * Cp + u * 8 + 4, acts_dt);
-            }
+    for (int layer = 0; layer < nlayers; ++layer) {
+        if (layer > 0) __syncthreads();  // every wave is done with the previous layer's matrix
+        const float* wl = fold_w + (long long)layer * nout * Cp;
+        for (int i = threadIdx.x; i < nout * Cp; i += 256) ws[i] = wl[i];
+        __syncthreads();
+        const void* acts = layer == 0 ? acts0 : (const void*)((const char*)acts_rest + (layer - 1) * slot_elems * esz);
+        if (live) {
+            for (int u = l16; u < Cp / 8; u += 16) {
+                f32x4 a, b;
+                if (acts_dt == 2) {
+                    const u32x4 raw = *(const u32x4*)((const unsigned short*)acts + row * Cp + u * 8);
+                    a = f32x4{__uint_as_float(raw[0] << 16), __uint_as_float(raw[0] & 0xffff0000u),
+                              __uint_as_float(raw[1] << 16), __uint_as_float(raw[1] & 0xffff0000u)};
+                    b = f32x4{__uint_as_float(raw[2] << 16), __uint_as_float(raw[2] & 0xffff0000u),
+                              __uint_as_float(raw[3] << 16), __uint_as_float(raw[3] & 0xffff0000u)};
+                } else {
+                    a = ld4(acts, row * Cp + u * 8, acts_dt);
+                    b = ld4(acts, row * Cp + u * 8 + 4, acts_dt);
+                }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if (j < nout) {
-                    const f32x4 q0 = *(const f32x4*)(ws + j * Cp + u * 8), q1 = *(const f32x4*)(ws + j * Cp + u * 8 + 4);
-                    acc[j] += a[0] * q0[0] + a[1] * q0[1] + a[2] * q0[2] + a[3] * q0[3] + b[0] * q1[0] + b[1] * q1[1] +
-                              b[2] * q1[2] + b[3] * q1[3];
+                for (int j = 0; j < 8; ++j) {
+                    if (j < nout) {
+                        const f32x4 q0 = *(const f32x4*)(ws + j * Cp + u * 8), q1 = *(const f32x4*)(ws + j * Cp + u * 8 + 4);
+                        acc[j] += a[0] * q0[0] + a[1] * q0[1] + a[2] * q0[2] + a[3] * q0[3] + b[0] * q1[0] +
+                                  b[1] * q1[1] + b[2] * q1[2] + b[3] * q1[3];
+                    }
                 }
             }
         }
@@ -408,9 +420,9 @@ static int waveglow_build(WaveglowHandle* h, WeightMap& W) {
         const bool fold = bf16 && env_or_int("MV_WG_FOLD", 1) != 0;
         h->fold = fold;
         std::vector<double> fold_bias(2 * n_half, 0.0);
+        std::vector<float> fold_all(fold ? (size_t)nl * 2 * n_half * h->Cp : 0, 0.f);
         if (fold) {
             f.res_only.resize(nl);
-            f.fold_w.assign(nl, nullptr);
             for (int j = 0; j < 2 * n_half; ++j) fold_bias[j] = eb->data[j];
         }
         for (int i = 0; i < nl; ++i) {
@@ -472,7 +484,7 @@ static int waveglow_build(WaveglowHandle* h, WeightMap& W) {
                 f.res_skip[i].alg_macs_per_n = (double)rsC * C;
             } else {
                 const int s0 = rsC - C;  // first skip row of res_skip_layers[i]
-                std::vector<float> fw((size_t)2 * n_half * h->Cp, 0.f);
+                float* fw = fold_all.data() + (size_t)i * 2 * n_half * h->Cp;
                 for (int j = 0; j < 2 * n_half; ++j) {
                     const float* ej = ew->data.data() + (size_t)j * C;
                     for (int cc = 0; cc < C; ++cc) {
@@ -482,7 +494,6 @@ static int waveglow_build(WaveglowHandle* h, WeightMap& W) {
                     }
                     for (int m = 0; m < C; ++m) fold_bias[j] += (double)ej[m] * rb->data[s0 + m];
                 }
-                if ((rc = upload(fw, &f.fold_w[i]))) return rc;
                 if (i < nl - 1) {
                     std::vector<float> rbias(rb->data.begin(), rb->data.begin() + C);
                     const int cfg = C % 256 == 0 ? env_or_int("MV_WG_RES_CFG", 0) : -1;
@@ -493,7 +504,7 @@ static int waveglow_build(WaveglowHandle* h, WeightMap& W) {
         }
         if (fold) {
             std::vector<float> fb(fold_bias.begin(), fold_bias.end());
-            if ((rc = upload(fb, &f.fold_b))) return rc;
+            if ((rc = upload(fb, &f.fold_b)) || (rc = upload(fold_all, &f.fold_w))) return rc;
         }
         // (executed work: with the folded skip path the res_skip layers cost C*C (+ 2*n_half*C on the VALU) per layer)
         macs_step += (double)n_half * C + (double)h->ncond * 2 * C * nl + (double)nl * 2 * C * C * ks +
@@ -554,6 +565,12 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
     // Likewise the residual stream H: it accumulates in float32, and every kernel that updates it also leaves a
     // bfloat16 copy (in the unused half of the ACTS buffer) for the next gated conv to stage by plain copies.
     unsigned short* Hb = opd == 2 ? (unsigned short*)((char*)ACTS + WaveglowHandle::al(bl * Cp * 2)) : nullptr;
+    // one fold launch per flow over all its layers' activations (needs them all kept: bf16 operand storage)
+    static const int fold_batch_env = env_or_int("MV_WG_FOLD_BATCH", 1);
+    const bool fold_batch = h->fold && opd == 2 && fold_batch_env;
+    const size_t slot = WaveglowHandle::al(bl * Cp * 2);
+    char* ACTS_REST = ws;  // slots 1 .. n_layers-1
+    if (h->fold) ws += (size_t)(nl - 1) * slot;
     float* AUDW = (float*)ws;
     // float output: the flow state lives directly in the caller's wav buffer
     float* AUD = out_format == MV_OUT_F32 ? (float*)wav : AUDW;
@@ -602,19 +619,25 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
             a.B = B;
             a.Tmax = Tmax;
             a.n_rows_per_frame = spf;
-            a.out[0] = ConvOut{ACTS, bsC, 0, (long long)spf * Cp, Cp, ACC_STORE, opd};
+            void* acts_i = fold_batch && i > 0 ? (void*)(ACTS_REST + (size_t)(i - 1) * slot) : ACTS;
+            a.out[0] = ConvOut{acts_i, bsC, 0, (long long)spf * Cp, Cp, ACC_STORE, opd};
             if ((rc = launch_layer(f.in_layers[i], sb, 2, a, stream, prof))) return rc;
-            SrcBind sa{ACTS, bsC, Cp, spf, 1.0f, opd};
+            SrcBind sa{acts_i, bsC, Cp, spf, 1.0f, opd};
             if (h->fold) {
                 const int nout = 2 * f.n_half;
                 const long long rows = (long long)B * L;
                 // (rows past a sequence's end hold stale activations: their sums are never read, wg_tail masks them)
-                if (prof) prof->begin(stream, "wg_skipfold_kernel", (double)nout * h->C * spf);
-                hipLaunchKernelGGL(wg_skipfold_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256),
-                                   (size_t)nout * Cp * 4, stream, (const void*)ACTS, opd, Cp, f.fold_w[i], nout, rows,
-                                   (float*)SKIP, i == 0 ? 0 : 1);
-                if (prof) prof->end(stream);
-                MV_HIP(hipGetLastError());
+                if (!fold_batch || i == nl - 1) {
+                    const int nfold = fold_batch ? nl : 1;
+                    if (prof) prof->begin(stream, "wg_skipfold_kernel", (double)nfold * nout * h->C * spf);
+                    hipLaunchKernelGGL(wg_skipfold_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256),
+                                       (size_t)nout * Cp * 4, stream, (const void*)ACTS, (const void*)ACTS_REST,
+                                       (long long)(slot / 2), nfold, opd, Cp,
+                                       f.fold_w + (fold_batch ? 0 : (size_t)i * nout * Cp), nout, rows, (float*)SKIP,
+                                       fold_batch || i == 0 ? 0 : 1);
+                    if (prof) prof->end(stream);
+                    MV_HIP(hipGetLastError());
+                }
                 if (i < nl - 1) {
                     LaunchArgs r;
                     r.lengths = lengths;
