@@ -234,3 +234,20 @@ def create_postnet(cfg: mv_postnet_cfg, state, device_index: int, precision: int
     check(lib().mv_postnet_create(C.byref(cfg), arr, len(keep), int(device_index), int(precision), C.byref(out)),
           "mv_postnet_create")
     return Handle(out.value, "postnet")
+
+
+def device_lengths(lengths, B, T, dev):
+    """int32 [B] frame counts on `dev`.  Host-side lengths are checked here; lengths that already live on the device
+    are clamped into [0, T] there instead (a check would cost a device->host sync in every call, and the kernels only
+    need the bound to stay inside their buffers)."""
+    import torch
+
+    lengths = torch.as_tensor(lengths)
+    if lengths.numel() != B:
+        raise RuntimeError("lengths must hold B frame counts in [0, T]")
+    if lengths.is_cuda:
+        return lengths.to(device=dev, dtype=torch.int32).clamp(0, T).contiguous()
+    lengths = lengths.to(torch.int32)
+    if B and (int(lengths.max()) > T or int(lengths.min()) < 0):
+        raise RuntimeError("lengths must hold B frame counts in [0, T]")
+    return lengths.to(dev, non_blocking=True).contiguous()

@@ -146,10 +146,7 @@ class Generator(nn.Module):
         dev = mel.device
         h = self._handle(dev)
         if lengths is not None:
-            lengths = torch.as_tensor(lengths, dtype=torch.int32)
-            if lengths.numel() != B or int(lengths.max()) > T or int(lengths.min()) < 0:
-                raise RuntimeError("lengths must hold B frame counts in [0, T]")
-            lengths = lengths.to(dev, non_blocking=True).contiguous()
+            lengths = _native.device_lengths(lengths, B, T, dev)
         pcm = out == "pcm16"
         wav = torch.empty((B, T * self.hop), dtype=torch.int16 if pcm else torch.float32, device=dev)
         ws = self._get_workspace(dev, h.workspace_bytes(B, T))

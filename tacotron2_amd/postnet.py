@@ -82,10 +82,7 @@ class Postnet(nn.Module):
         dev = xin.device
         h = self.native_handle(dev)
         if lengths is not None:
-            lengths = torch.as_tensor(lengths, dtype=torch.int32)
-            if lengths.numel() != B or int(lengths.max()) > T or int(lengths.min()) < 0:
-                raise RuntimeError("lengths must hold B frame counts in [0, T]")
-            lengths = lengths.to(dev, non_blocking=True).contiguous()
+            lengths = _native.device_lengths(lengths, B, T, dev)
         y = torch.empty_like(xin)
         nbytes = h.workspace_bytes(B, T)
         ws = self._workspace.get(dev)

@@ -135,10 +135,7 @@ class WaveGlow(nn.Module):
             if tuple(n.shape) != s:
                 raise RuntimeError(f"noise tensor of shape {tuple(n.shape)}, expected {s}")
         if lengths is not None:
-            lengths = torch.as_tensor(lengths, dtype=torch.int32)
-            if lengths.numel() != B or int(lengths.max()) > T or int(lengths.min()) < 0:
-                raise RuntimeError("lengths must hold B frame counts in [0, T]")
-            lengths = lengths.to(dev).contiguous()
+            lengths = _native.device_lengths(lengths, B, T, dev)
         h = self._handle(dev)
         pcm = out == "pcm16"
         wav = torch.empty((B, T * 256), dtype=torch.int16 if pcm else torch.float32, device=dev)
