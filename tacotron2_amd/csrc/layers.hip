@@ -298,7 +298,7 @@ int launch_layer(const Layer& L, const SrcBind* srcs, int nsrc, const LaunchArgs
     p.epi_lds = epi_lds_on && L.bf16 && unit_ok(a.out[0]) && (!two || (a.split % mo == 0 && unit_ok(a.out[1]))) &&
                 (L.epi == EPI_LINEAR || !two) && a.resid_batch_stride % 8 == 0;
     // bfloat16 storage (dtype code 2) is for tensors that are only ever MFMA operands: a plain copy on the way in,
-    // the coalescing epilogue's raw store on the way out
+    // a plain store on the way out
     for (int i = 0; i < L.npass; ++i) {
         const SrcBind& sb = srcs[L.pass[i].src];
         if (sb.f16 == 2 && !(L.bf16 && sb.slope == 1.0f)) {
@@ -306,7 +306,7 @@ int launch_layer(const Layer& L, const SrcBind* srcs, int nsrc, const LaunchArgs
             return MV_EINVAL;
         }
     }
-    if (a.out[0].f16 == 2 && !((p.epi_lds || !L.bf16) && !two && !a.resid && a.out[0].mode == ACC_STORE)) {
+    if (a.out[0].f16 == 2 && !(!two && !a.resid && a.out[0].mode == ACC_STORE)) {
         set_error("launch_layer: a bfloat16 output must be a plain store (single output, no residual, no accumulate)");
         return MV_EINVAL;
     }
