@@ -184,3 +184,27 @@ def test_more_sequences_than_the_window_table_holds(gen_bf16):
             assert 10 * np.log10(np.sum(ref.astype(np.float64) ** 2) / max(err, 1e-30)) >= 40.0
             checked += 1
     assert checked == 3
+
+
+def test_bench_batch_bf16_against_fp32_mode(gen_fp32, gen_bf16):
+    """BASELINE.json configs[1] at full size (32 mels of 2-10 s): the oracle would take minutes here, but the two
+    precisions run through disjoint kernels (layer-by-layer exact-fp32 MFMA vs the fused bf16 kernels), and fp32 mode
+    is pinned to the reference by the goldens above -- every utterance of the batch must meet the bf16 bar against
+    it, the samples past its end must be zero, and PCM16 must be the reference's quantisation of the float output."""
+    lens = np.sort(synth.synthetic_lengths(32, 1234))[::-1].copy()
+    T = int(lens.max())
+    x = torch.full((32, 80, T), synth.MEL_PAD_VALUE)
+    for b, n in enumerate(lens):
+        x[b, :, :n] = torch.from_numpy(np.asarray(synth.synthetic_mel(int(n), 1234 + b)))
+    xg = x.cuda()
+    ln = [int(n) for n in lens]
+    ref = gen_fp32(xg, lengths=ln)[:, 0].cpu().numpy()
+    got = gen_bf16(xg, lengths=ln)[:, 0].cpu().numpy()
+    pcm = gen_bf16(xg, lengths=ln, out="pcm16")[:, 0].cpu().numpy()
+    worst = 1e9
+    for b, n in enumerate(ln):
+        r, g = ref[b, :n * 256].astype(np.float64), got[b, :n * 256].astype(np.float64)
+        worst = min(worst, 10 * np.log10((r ** 2).sum() / max(((r - g) ** 2).sum(), 1e-300)))
+        assert not got[b, n * 256:].any() and not ref[b, n * 256:].any()
+    assert worst >= 40.0, worst
+    assert np.array_equal(pcm.ravel(), np.asarray(c_oracle.pcm16(got)).ravel())
