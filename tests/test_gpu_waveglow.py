@@ -99,3 +99,23 @@ def test_pcm16_and_errors():
         m.infer(mel.cpu(), sigma=0.1)
     with pytest.raises(RuntimeError):
         m.infer(mel, sigma=0.1, noise=noise[:2])
+
+
+def test_full_size_bf16_against_fp32_mode():
+    """BASELINE.json configs[2] at full size (512 channels, a 500-frame mel, here two ragged sequences): fp32 mode is
+    pinned to the reference by the goldens above; bf16 mode (bfloat16 operand tensors, folded skip path, fast gate)
+    runs through other kernels and must meet its bar against it per sequence, with zeros past each end."""
+    cfg = _cfg(512)
+    m = _model(cfg, 0, "fp32")
+    B, T, lengths = 2, 500, [500, 271]
+    mel = torch.full((B, 80, T), synth.MEL_PAD_VALUE)
+    for b, n in enumerate(lengths):
+        mel[b, :, :n] = torch.from_numpy(synth.synthetic_mel(n, 70 + b))
+    mel = mel.cuda()
+    noise = [torch.from_numpy(n) for n in synth.waveglow_noise(cfg, B, T, 99)]
+    ref = m.infer(mel, sigma=0.666, noise=noise, lengths=lengths).cpu().numpy()
+    m.precision = "bf16"
+    got = m.infer(mel, sigma=0.666, noise=noise, lengths=lengths).cpu().numpy()
+    for b, n in enumerate(lengths):
+        assert _snr(ref[b, :n * 256], got[b, :n * 256]) >= 40.0, (b, _snr(ref[b, :n * 256], got[b, :n * 256]))
+        assert not got[b, n * 256:].any() and not ref[b, n * 256:].any()
