@@ -117,15 +117,6 @@ __device__ __forceinline__ void lds_bias(f32x4 (&bias)[TM], const float* bias_s,
     for (int tm = 0; tm < TM; ++tm) bias[tm] = *(const f32x4*)(bias_s + conv * C + chl + 4 * tm);
 }
 
-// Pin the point where outstanding loads of `v` are waited for: the compiler's s_waitcnt for a value lands at
-// its first use, and a first use AFTER a conditional block of younger loads degrades to vmcnt(0) -- i.e. it
-// would wait for the prefetched window too.
-template <int N>
-__device__ __forceinline__ void settle(const f32x4 (&v)[N]) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) asm volatile("" ::"v"(v[i]));
-}
-
 // leaky_relu on 4 values as max(x, slope*x) (0 < slope <= 1): two packed multiplies + four v_max
 __device__ __forceinline__ f32x4 lrelu4(const f32x4& v, float slope) {
     const f32x4 s = v * slope;
