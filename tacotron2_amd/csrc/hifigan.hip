@@ -281,8 +281,10 @@ int build_convT_layer(Layer* L, const HostTensor* w, const HostTensor* b, int Ci
     if (force_cfg < 0 && bf16) {  // the low-channel upsamplers are HBM-bound: their tile shape is tuned on its own
         const int M = u * cout_pad;
         static const int c128 = env_or("MV_CFG_UPS_M128", -1), c64 = env_or("MV_CFG_UPS_M64", -1);
+        static const int cbig = env_or("MV_CFG_UPS_M256", -1);
         if (M == 128) force_cfg = c128;
         if (M == 64) force_cfg = c64;
+        if (M % 256 == 0) force_cfg = cbig;
     }
     return build_layer(L, {s}, u * cout_pad, bias, bf16, EPI_LINEAR, force_cfg);
 }
