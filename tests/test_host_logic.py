@@ -192,3 +192,16 @@ def test_two_rank_gloo_sharding_covers_the_corpus_once():
     # single-process run gives the same corpus fingerprint
     res, st = batch.synthesize_shard(_FakeVocoder(), mels, lengths, max_batch=8, width=8)
     assert abs(batch.gather_stats(st).checksum - outs[0][5]) < 1e-6
+
+
+def test_device_lengths_host_side_check():
+    """Host-side lengths are validated before anything is launched (device-side ones are clamped on the device)."""
+    import torch
+
+    from tacotron2_amd import _native
+
+    ok = _native.device_lengths([3, 0, 7], 3, 7, torch.device("cpu"))
+    assert ok.dtype == torch.int32 and ok.tolist() == [3, 0, 7]
+    for bad in ([3, 8, 1], [3, -1, 1], [3, 1]):
+        with pytest.raises(RuntimeError):
+            _native.device_lengths(bad, 3, 7, torch.device("cpu"))
