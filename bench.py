@@ -1,25 +1,38 @@
 #!/usr/bin/env python3
 """bench.py -- audio-seconds synthesized per wall-second (22.05 kHz) on N MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp32] [--model hifigan|waveglow]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp32] [--model hifigan|waveglow|postnet]
 
-Workload (BASELINE.json configs[1]): HiFi-GAN V1 generator, one batch of
-32 synthetic 80-bin mels of 2-10 s (T_i = 2*U{86..430} frames, numpy default_rng(1234+rank)),
-sorted by length, right-padded with the mel floor, vocoded in ONE call with a `lengths` vector
-(tiles past a sequence's end exit at once, so padding costs no arithmetic).  A "step" is one such
-call; weights are synthetic (tacotron2_amd.synth, seed 0); mels are resident in HBM before the
-timed region.  Audio seconds are counted on TRUE lengths only.  For N > 1 every rank vocodes its
-own batch (weak scaling, no data-path collective); RCCL only reduces the timing.
+Headline workload (BASELINE.json configs[1]): HiFi-GAN V1 generator, one batch of
+32 synthetic 80-bin mels of 2-10 s (T_i = 2*U{86..430} frames, numpy default_rng(1234+rank)), sorted by
+length, right-padded with the mel floor, vocoded in ONE call with a `lengths` vector (windows past a
+sequence's end are never visited, so padding costs no arithmetic).  A "step" is one such call; weights are
+synthetic (tacotron2_amd.synth, seed 0); mels are resident in HBM before the timed region.  Audio seconds are
+counted on TRUE lengths only.
 
-The JSON line also carries
-  roofline      dominant MFMA kernel: algorithmic FLOP/launch / mean launch time from HIP events
-                recorded by the library around every launch (mv_profile_begin/end)
-  cpu_baseline  the oracle's PyTorch-CPU restatement of the reference generator (oracle/torch_ref.py)
-                timed on this host on the configs[0] input (one 80x500 mel, batch 1)
+Ranks: with WORLD_SIZE in the environment (torch.distributed.run) this process is one rank.  Without it,
+`--gpus N` with N > 1 makes this process a launcher: it starts N fresh rank processes (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* set, 127.0.0.1 rendezvous) before anything touches a GPU, relays rank 0's JSON line and
+exits non-zero if a rank fails or the node has fewer than N devices.  Every rank vocodes its own batch (weak
+scaling, no data-path collective); RCCL only carries the barrier and the max-time / sum-audio reduction.
+
+The JSON line carries, besides the contract's fields,
+  roofline      dominant MFMA kernel BY ROCPROF SYMBOL: algorithmic FLOP of all its launches / their summed HIP-event
+                time (recorded by the library around every launch on the launch stream, mv_profile_begin/end), so the
+                figure can be re-derived from profiles/*_kernel_stats.csv; `by_detail` splits the symbol's launches
+  cpu_baseline  the oracle's PyTorch-CPU restatement of the reference generator (oracle/torch_ref.py) timed on
+                this host on the configs[0] input (one 80x500 mel, batch 1); rank 0, N = 1 only
+  fp32          the same batch through MV_PREC_FP32 (the reference's own arithmetic; configs[1] "bf16 and fp32")
+  waveglow      BASELINE configs[2]: WaveGlow 12 flows x 8 layers x 512 ch, 80x500 mels, sigma 0.666, noise from
+                torch.manual_seed(1234); records B1 and B8 (bf16 operands) and B1_fp32
+  pcie          configs[3] on this one GPU with host buffers on both sides (host mels -> PCM16 on the host)
+(the last four at N = 1 only; --no-extras skips fp32 / waveglow / pcie).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,19 +45,62 @@ SR = 22050.0
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--dtype", default=os.environ.get("MELVOC_BENCH_DTYPE", "bf16"), choices=["bf16", "fp32"])
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--model", default="hifigan", choices=["hifigan", "waveglow", "postnet"])
-    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--batch", type=int, default=None, help="utterances per step (default 32; waveglow 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    return ap.parse_args()
+    ap.add_argument("--no-extras", action="store_true", help="skip the fp32 / waveglow / pcie records")
+    ap.add_argument("--rows", action="store_true", help="per-kernel table on stderr")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch / rendezvous / reduce path only: gloo on the CPU, the step is a no-op (tests)")
+    return ap.parse_args(argv)
 
 
+# ---------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without torch.distributed.run
+def launch_ranks(args, argv):
+    if not args.dry_run:
+        import torch
+
+        have = torch.cuda.device_count()  # counts devices without initialising HIP in this (launcher) process
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but this node shows {have} device(s)", file=sys.stderr)
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode]
+    deadline = time.time() + 120
+    for p in procs[1:]:
+        try:
+            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            p.kill()  # this exact child
+            rcs.append(-9)
+    sys.stdout.write(out0 or "")
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print(f"bench.py: ranks failed: {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------------
 def make_batch(torch, B, seed, dev):
     from tacotron2_amd import synth
 
@@ -80,31 +136,191 @@ def cpu_baseline(torch):
                       f"synthetic mel, batch 1, median of {len(times)} calls, {threads} threads of {cores} host CPUs"}
 
 
-def profiled_traffic(kernel_name, args):
-    """HBM-side bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes (profiles/*_traffic.json),
-    valid for the default bf16 HiFi-GAN batch only; None when there is no matching measurement."""
-    if args.model != "hifigan" or args.dtype != "bf16" or args.batch != 32:
-        return None
+def profiled_traffic(symbol, model, dtype, batch):
+    """HBM-side bytes per launch of `symbol` from the committed rocprofv3 PMC passes (newest profiles/*_traffic.json
+    whose `_workload` matches); None when there is no matching measurement."""
     import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_traffic.json")))
-    if not files:
-        return None
-    with open(files[-1]) as f:
-        table = json.load(f)
-    for k, v in table.items():
-        if not k.startswith("_") and kernel_name.startswith(k):
+
+    want = f"{model}/{dtype}/B{batch}"
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
+        with open(path) as f:
+            table = json.load(f)
+        if table.get("_workload") != want:
+            continue
+        v = table.get(symbol)
+        if v:
             return v["bytes_per_launch"]
     return None
 
 
-def main():
-    args = parse()
+def build_model(torch, model, dtype, batch, rank, dev):
+    """-> (module, run(), frames per step, workload string, batch)"""
+    from tacotron2_amd import synth
+
+    if model == "hifigan":
+        from tacotron2_amd.hifigan import AttrDict, Generator
+
+        B = batch or 32
+        m = Generator(AttrDict(synth.HIFIGAN_V1), precision=dtype)
+        sd = synth.hifigan_state(synth.HIFIGAN_V1, 0)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        m.eval()
+        m = m.to(dev)
+        mel, lengths_d, lengths = make_batch(torch, B, 1234 + rank, dev)
+        run = lambda: m(mel, lengths=lengths_d)  # noqa: E731
+        workload = f"HiFi-GAN V1 (config_v1), batch {B} synthetic 80-bin mels of 2-10 s, one length-masked call per step"
+    elif model == "postnet":
+        # SURVEY §8f rank 2: the Tacotron2 Postnet (+ input) of model.py:717 on the same batch of mels; its
+        # "audio seconds" are the seconds of speech the frames stand for (256 samples each)
+        from tacotron2_amd.postnet import Postnet
+
+        B = batch or 32
+        m = Postnet(synth.POSTNET_TC2, 0, precision=dtype)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.postnet_state(synth.POSTNET_TC2, 0).items()},
+                          strict=False)
+        m = m.eval().to(dev)
+        mel, lengths_d, lengths = make_batch(torch, B, 1234 + rank, dev)
+        run = lambda: m(mel, lengths=lengths_d, add_input=True)  # noqa: E731
+        workload = (f"Tacotron2 Postnet (5 x Conv1d k5 512 ch + folded BatchNorm + tanh, + input), batch {B} "
+                    f"synthetic 80-bin mels of 2-10 s")
+    else:
+        from tacotron2_amd.waveglow import WaveGlow
+
+        B = batch or 1
+        m = WaveGlow(**synth.WAVEGLOW_512)
+        m = WaveGlow.remove_weightnorm(m)
+        sd = synth.waveglow_state(synth.WAVEGLOW_512, 0)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        del sd
+        m.eval().to(dev)
+        m.precision = dtype
+        lengths = np.full(B, 500, np.int32)
+        mel = torch.from_numpy(np.stack([synth.synthetic_mel(500, 1234 + rank * 100 + b) for b in range(B)])).to(dev)
+        torch.manual_seed(1234)
+        run = lambda: m.infer(mel, sigma=0.666)  # noqa: E731
+        workload = (f"WaveGlow 12 flows x WN 8 layers x 512 ch, {B} x 80x500 mel, sigma 0.666, noise drawn by torch "
+                    f"on the device after manual_seed(1234)")
+    return m, run, float(lengths.sum()), workload, B
+
+
+def roofline_of(torch, m, run, frames, dev, model, dtype, batch, nprof, show_rows):
+    h = m.native_handle(dev)
+    h.profile_begin()
+    for _ in range(nprof):
+        run()
+    torch.cuda.synchronize()
+    rows = h.profile_end()
+    if not rows:
+        return None
+    by_sym = {}
+    for r in rows:
+        by_sym.setdefault(r["name"], []).append(r)
+    tot = lambda rs, k: sum(r[k] for r in rs)  # noqa: E731
+    if show_rows:
+        for r in sorted(rows, key=lambda r: -r["ms"]):
+            print("# %-86s %-16s launches/step %3d  ms/step %8.3f  TFLOP/s %7.1f" % (
+                r["name"][:86], r["detail"], r["launches"] // nprof, r["ms"] / nprof,
+                2.0 * r["macs_per_frame"] * frames / max(r["ms"], 1e-9) / 1e9), file=sys.stderr)
+    sym, rs = max(by_sym.items(), key=lambda kv: tot(kv[1], "ms"))
+    ms, launches = tot(rs, "ms"), tot(rs, "launches")
+    flops = 2.0 * tot(rs, "macs_per_frame") * frames  # algorithmic, over all recorded launches of the symbol
+    achieved = flops / (ms * 1e-3) / 1e12
+    peak = PEAK_TFLOPS[dtype]
+    all_ms = tot(rows, "ms")
+    all_flops = 2.0 * tot(rows, "macs_per_frame") * frames
+    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": profiled_traffic(sym, model, dtype, batch), "kernel": sym,
+            "launches_per_step": launches // nprof, "avg_launch_us": round(ms * 1e3 / launches, 2),
+            "flop_per_launch": round(flops / launches),
+            "share_of_mfma_kernel_time": round(ms / all_ms, 3),
+            "all_conv_kernels_tflops": round(all_flops / (all_ms * 1e-3) / 1e12, 2),
+            "by_detail": [{"detail": r["detail"], "launches_per_step": r["launches"] // nprof,
+                           "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2),
+                           "tflops": round(2.0 * r["macs_per_frame"] * frames / (r["ms"] * 1e-3) / 1e12, 2)}
+                          for r in sorted(rs, key=lambda r: -r["ms"])]}
+
+
+def timed(torch, run, steps, warmup, barrier):
+    for _ in range(warmup):
+        run()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    barrier()
+    return time.perf_counter() - t0
+
+
+def side_record(torch, model, dtype, batch, dev, steps, warmup, show_rows):
+    """One of the secondary records (N = 1): same measurement as the headline on another model / precision."""
+    m, run, frames, workload, B = build_model(torch, model, dtype, batch, 0, dev)
+    dt = timed(torch, run, steps, warmup, torch.cuda.synchronize)
+    audio_s = frames * 256 / SR
+    macs = m.macs_per_frame(dev)
+    peak_audio = PEAK_TFLOPS[dtype] * 1e12 / (2.0 * macs * SR / 256)
+    rec = {"value": round(audio_s * steps / dt, 2), "unit": "audio-s/s", "ms_per_step": round(dt / steps * 1e3, 3),
+           "steps": steps, "warmup": warmup, "dtype": dtype, "workload": workload,
+           "gflop_per_audio_s": round(2.0 * macs * SR / 256 / 1e9, 3),
+           "frac_of_mfma_roofline": round(audio_s * steps / dt / peak_audio, 4),
+           "roofline": roofline_of(torch, m, run, frames, dev, model, dtype, B, max(1, min(steps, 3)), show_rows)}
+    del m, run
+    torch.cuda.empty_cache()
+    return rec
+
+
+def pcie_record(torch, dev):
+    """BASELINE configs[3] on this one GPU: host mels -> pinned -> H2D -> vocode -> PCM16 -> D2H -> host arrays, the
+    pipeline of tacotron2_amd.batch.synthesize_shard (never `value`: it includes PCIe and host work)."""
+    from tacotron2_amd import batch as vb
+    from tacotron2_amd import do_syn_batch, synth
+
+    n = 2000
+    voc = do_syn_batch.build_vocoder("synthetic-hifigan", dev, "bf16")
+    lens = synth.synthetic_lengths(n, 1234)
+    base = [synth.synthetic_mel(430, 7 + i) for i in range(16)]  # 16 distinct mels, cut to length: the host-side
+    mels = [base[i % 16][:, : int(T)] for i, T in enumerate(lens)]  # generator is not what is being timed
+    seen = [0]
+
+    def sink(i, pcm):  # what a WAV writer would be handed: a view of the pinned download slot
+        seen[0] += int(pcm.shape[0])
+
+    vb.synthesize_shard(voc, mels[:64], device=dev, sink=sink)  # warm-up (workspace growth, pinned slots)
+    seen[0] = 0
+    _, st = vb.synthesize_shard(voc, mels, device=dev, sink=sink)
+    audio_s = float(lens.sum()) * 256 / SR
+    assert seen[0] == int(lens.sum()) * 256
+    return {"value": round(audio_s / st.wall_seconds, 2), "unit": "audio-s/s", "utterances": n,
+            "wall_s": round(st.wall_seconds, 3), "calls": st.calls, "checksum": st.checksum,
+            "workload": "do_syn-style batch on one GPU (BASELINE configs[3] shape): 2000 synthetic utterances of "
+                        "2-10 s, host float32 mels -> int16 PCM in pinned host memory handed to a per-utterance "
+                        "sink, length-bucketed (<= 32 per call), pad / H2D / vocode / D2H overlapped"}
+
+
+def run_rank(args):
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_run:
+        # the launch / rendezvous / reduction path with no GPU: what tests/test_host_logic.py drives at world 2
+        if world > 1:
+            dist.init_process_group("gloo")
+        t = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
+        a = torch.tensor([1.0], dtype=torch.float64)
+        if world > 1:
+            dist.barrier()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.all_reduce(a, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            print(json.dumps({"metric": "audio-seconds synthesized per wall-second (22.05 kHz)", "value": None,
+                              "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "dry_run": True, "max_time": float(t.item()), "sum_audio": float(a.item())}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return 0
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
@@ -112,49 +328,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    from tacotron2_amd import synth
-
-    if args.model == "hifigan":
-        from tacotron2_amd.hifigan import AttrDict, Generator
-
-        model = Generator(AttrDict(synth.HIFIGAN_V1), precision=args.dtype)
-        sd = synth.hifigan_state(synth.HIFIGAN_V1, 0)
-        model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
-        model.eval()
-        model = model.to(dev)
-        mel, lengths_d, lengths = make_batch(torch, args.batch, 1234 + rank, dev)
-        run = lambda: model(mel, lengths=lengths_d)  # noqa: E731
-        workload = (f"HiFi-GAN V1 (config_v1), batch {args.batch} synthetic 80-bin mels of 2-10 s, one "
-                    f"length-masked call per step")
-    elif args.model == "postnet":
-        # the Tacotron2 Postnet (+ input) of model.py:717 on the same batch of mels; its
-        # "audio seconds" are the seconds of speech the frames stand for (256 samples each)
-        from tacotron2_amd.postnet import Postnet
-
-        model = Postnet(synth.POSTNET_TC2, 0, precision=args.dtype)
-        model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.postnet_state(synth.POSTNET_TC2, 0).items()},
-                              strict=False)
-        model = model.eval().to(dev)
-        mel, lengths_d, lengths = make_batch(torch, args.batch, 1234 + rank, dev)
-        run = lambda: model(mel, lengths=lengths_d, add_input=True)  # noqa: E731
-        workload = (f"Tacotron2 Postnet (5 x Conv1d k5 512 ch + folded BatchNorm + tanh, + input), batch "
-                    f"{args.batch} synthetic 80-bin mels of 2-10 s")
-    else:
-        from tacotron2_amd.waveglow import WaveGlow
-
-        model = WaveGlow(**synth.WAVEGLOW_512)
-        model = WaveGlow.remove_weightnorm(model)
-        sd = synth.waveglow_state(synth.WAVEGLOW_512, 0)
-        model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
-        model.eval().to(dev)
-        model.precision = args.dtype
-        B = 1 if args.batch == 32 else args.batch
-        lengths = np.full(B, 500, np.int32)
-        mel = torch.from_numpy(np.stack([synth.synthetic_mel(500, 1234 + rank * 100 + b) for b in range(B)])).to(dev)
-        torch.manual_seed(1234)
-        run = lambda: model.infer(mel, sigma=0.666)  # noqa: E731
-        workload = f"WaveGlow 12 flows x WN 8 layers x 512 ch, {B} x 80x500 mel, sigma 0.666"
-    frames = float(lengths.sum())
+    model, run, frames, workload, B = build_model(torch, args.model, args.dtype, args.batch, rank, dev)
     audio_s = frames * 256 / SR
 
     def barrier():
@@ -162,14 +336,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        run()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
-    barrier()
-    dt = time.perf_counter() - t0
+    dt = timed(torch, run, args.steps, args.warmup, barrier)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -181,36 +348,11 @@ def main():
         total_audio = audio_s
     value = total_audio * args.steps / dt
 
-    roofline = None
-    if rank == 0 and not args.no_profile:
-        h = model.native_handle(dev)
-        nprof = max(1, min(args.steps, 5))
-        h.profile_begin()
-        for _ in range(nprof):
-            run()
-        torch.cuda.synchronize()
-        rows = h.profile_end()
-        rows.sort(key=lambda r: -r["ms"])
-        if os.environ.get("MELVOC_BENCH_ROWS"):
-            for r in rows:
-                print("# %-48s launches/step %3d  ms/step %8.3f  TFLOP/s %7.1f" % (
-                    r["name"], r["launches"] // nprof, r["ms"] / nprof,
-                    2.0 * r["macs_per_frame"] * frames / max(r["ms"], 1e-9) / 1e9), file=sys.stderr)
-        top = rows[0]
-        flops = 2.0 * top["macs_per_frame"] * frames  # over all recorded launches of that kernel
-        achieved = flops / (top["ms"] * 1e-3) / 1e12
-        peak = PEAK_TFLOPS[args.dtype]
-        all_ms = sum(r["ms"] for r in rows)
-        all_flops = sum(2.0 * r["macs_per_frame"] * frames for r in rows)
-        roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": profiled_traffic(top["name"], args), "kernel": top["name"],
-                    "launches_per_step": top["launches"] // nprof,
-                    "avg_launch_us": round(top["ms"] * 1e3 / top["launches"], 2),
-                    "flop_per_launch": round(flops / top["launches"]),
-                    "share_of_mfma_kernel_time": round(top["ms"] / all_ms, 3),
-                    "all_conv_kernels_tflops": round(all_flops / (all_ms * 1e-3) / 1e12, 2)}
-
     if rank == 0:
+        roofline = None
+        if not args.no_profile:
+            roofline = roofline_of(torch, model, run, frames, dev, args.model, args.dtype, B,
+                                   max(1, min(args.steps, 5)), args.rows)
         macs = model.macs_per_frame(dev)
         peak_audio = PEAK_TFLOPS[args.dtype] * 1e12 / (2.0 * macs * SR / 256)
         line = {
@@ -232,13 +374,39 @@ def main():
             "gflop_per_audio_s": round(2.0 * macs * SR / 256 / 1e9, 3),
             "frac_of_mfma_roofline": round(value / world / peak_audio, 4),
             "roofline": roofline,
-            "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(torch),
+            "cpu_baseline": None,
         }
+        extras = world == 1 and not args.no_extras and args.model == "hifigan" and args.dtype == "bf16" \
+            and args.batch in (None, 32)
+        if extras:
+            del model, run
+            torch.cuda.empty_cache()
+            line["fp32"] = side_record(torch, "hifigan", "fp32", None, dev, 10, 2, args.rows)
+            line["waveglow"] = {
+                "B1": side_record(torch, "waveglow", "bf16", 1, dev, 60, 5, args.rows),
+                "B8": side_record(torch, "waveglow", "bf16", 8, dev, 10, 2, args.rows),
+                "B1_fp32": side_record(torch, "waveglow", "fp32", 1, dev, 5, 1, args.rows),
+            }
+            try:
+                line["pcie"] = pcie_record(torch, dev)
+            except Exception as e:  # secondary: never lose the headline to it
+                line["pcie"] = {"error": repr(e)[:200]}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(torch)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args, argv)
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

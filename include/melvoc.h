@@ -16,6 +16,8 @@
  *     The caller owns mel, lengths, noise, output and workspace (device memory).
  *   - a handle owns only its repacked weights; it is bound to the device it was created on and
  *     is not re-entrant (callers serialise calls on one handle; distinct handles are independent).
+ *     The library keeps no process-global mutable state besides the per-thread error string and reads
+ *     no environment variables: what can be tuned is in mv_options, per handle.
  *   - the library needs a gfx950 device: there is no CPU fallback (mv_backend() == 1 always).
  */
 #ifndef MELVOC_H
@@ -97,6 +99,18 @@ typedef struct mv_postnet_cfg {
     float bn_eps;        /* nn.BatchNorm1d default 1e-5 */
 } mv_postnet_cfg;
 
+/* Per-handle options of mv_*_create (NULL = the defaults, which are what bench.py measures).  They select
+ * other kernels for the same arithmetic; every setting meets the same parity bars.  No counterpart in the
+ * reference.  Zero-initialise, then call mv_default_options() before changing single fields. */
+typedef struct mv_options {
+    int fuse;    /* HiFi-GAN, MV_PREC_BF16: 2 (default) fused ResBlock + whole-stage kernels, 1 fused ResBlock
+                    kernels only, 0 one convolution per launch (the MV_PREC_FP32 structure) */
+    int io16;    /* MV_PREC_BF16: 1 (default) activations between kernels stored as float16, 0 as float32 */
+    int wg_fold; /* WaveGlow, MV_PREC_BF16: 1 (default) skip halves of res_skip folded with the end conv
+                    (end(sum_i skip_i) = sum_i (W_end W_skip_i) acts_i), 0 the reference's split (glow.py:168-173) */
+} mv_options;
+MV_API void mv_default_options(mv_options* opt);
+
 /* 1 = gfx950 HIP kernels.  (0 would be a CPU backend; this library has none.) */
 MV_API int mv_backend(void);
 
@@ -108,12 +122,13 @@ MV_API const char* mv_last_error(void);
  * Folds weight-norm, repacks every convolution into MFMA fragment order and uploads it to
  * HIP device `device`.  `precision` is MV_PREC_*. */
 MV_API int mv_hifigan_create(const mv_hifigan_cfg* cfg, const mv_tensor* weights, int n_weights, int device,
-                      int precision, mv_handle* out);
+                      int precision, const mv_options* options, mv_handle* out);
 
 /* Replaces: Generator.forward (hifigan/models.py:149-165) as called at do_syn.py:278,391 and
  * do_tts.py:351.
  *   mel      device float32 [B][num_mels][Tmax], C-contiguous (the reference's layout)
- *   lengths  device int32 [B] true frame counts (<= Tmax) or NULL (all Tmax).  Every layer
+ *   lengths  device int32 [B] true frame counts or NULL (all Tmax); every kernel clamps the entries it reads
+ *            into [0, Tmax], so a bad entry cannot take an access out of the buffers.  Every layer
  *            zero-pads at each sequence's own end, so row b equals the reference's batch-1
  *            output for mel[b, :, :lengths[b]]; samples past lengths[b]*hop are written as 0.
  *   wav      device [B][Tmax*hop], float32 (MV_OUT_F32) or int16 (MV_OUT_PCM16); hop = prod(rates)
@@ -125,7 +140,7 @@ MV_API int mv_hifigan_forward(mv_handle h, const float* mel, const int32_t* leng
  * (do_syn.py:147-150, waveglow/glow.py:179-205,297-313).  W^-1 of every Invertible1x1Conv is
  * computed here once in fp32 (glow.py:89-95 caches it on first use). */
 MV_API int mv_waveglow_create(const mv_waveglow_cfg* cfg, const mv_tensor* weights, int n_weights, int device,
-                       int precision, mv_handle* out);
+                       int precision, const mv_options* options, mv_handle* out);
 
 /* Replaces: WaveGlow.infer (waveglow/glow.py:251-295) as called at do_syn.py:276,389 and
  * do_tts.py:349.  The kernels never draw random numbers: the caller passes the unit-variance
@@ -144,7 +159,7 @@ MV_API int mv_waveglow_infer(mv_handle h, const float* mel, const int32_t* lengt
  * "convolutions.<i>.1.weight|bias|running_mean|running_var", folded into the conv here (eval mode; dropout
  * is inactive in eval, model.py:172-173). */
 MV_API int mv_postnet_create(const mv_postnet_cfg* cfg, const mv_tensor* weights, int n_weights, int device,
-                      int precision, mv_handle* out);
+                      int precision, const mv_options* options, mv_handle* out);
 
 /* Replaces: Postnet.forward (model.py:170-174) and, with add_input != 0, the call site
  * `par_out + self.postnet(par_out)` (model.py:717) whose result do_syn.py:380-391 hands to the vocoder.
@@ -172,11 +187,12 @@ MV_API int mv_pcm16(const float* wav, size_t n, int16_t* pcm, void* stream);
 /* ---- measurement: per-launch HIP-event timing of the MFMA kernels (bench.py's roofline figure).
  * No counterpart in the reference.  After mv_profile_begin(h) every convolution launch of the
  * following forward/infer calls is bracketed by hipEventRecord on the call's stream;
- * mv_profile_end(h, ...) synchronises those events, sums them per kernel instantiation and
+ * mv_profile_end(h, ...) synchronises those events, sums them per (kernel symbol, detail) and
  * switches profiling off.  macs_per_frame is the ALGORITHMIC (un-padded) multiply-accumulate count
  * per mel frame summed over the recorded launches: flops = 2 * macs_per_frame * frames of the batch. */
 typedef struct mv_profile_row {
-    char name[96];
+    char name[192];  /* the kernel's symbol as rocprofv3 --kernel-trace --stats prints it */
+    char detail[32]; /* which of that symbol's launches ("k=11", "+conv_post", ...; "" if there is one kind) */
     int launches;
     double ms;
     double macs_per_frame;

@@ -22,7 +22,7 @@ EXPORTS = (
     "mv_backend", "mv_last_error", "mv_hifigan_create", "mv_hifigan_forward", "mv_waveglow_create",
     "mv_waveglow_infer", "mv_workspace_bytes", "mv_hop", "mv_macs_per_frame", "mv_destroy", "mv_pcm16",
     "mv_test_conv1d", "mv_test_conv_transpose1d", "mv_profile_begin", "mv_profile_end",
-    "mv_postnet_create", "mv_postnet_forward",
+    "mv_postnet_create", "mv_postnet_forward", "mv_default_options",
 )
 
 
@@ -65,8 +65,26 @@ class mv_postnet_cfg(C.Structure):
                 ("n_convolutions", C.c_int), ("bn_eps", C.c_float)]
 
 
+class mv_options(C.Structure):
+    _fields_ = [("fuse", C.c_int), ("io16", C.c_int), ("wg_fold", C.c_int)]
+
+
+def make_options(options):
+    """dict of mv_options fields (missing ones keep the library's defaults) -> mv_options, or None for NULL."""
+    if not options:
+        return None
+    o = mv_options()
+    lib().mv_default_options(C.byref(o))
+    for k, v in options.items():
+        if k not in ("fuse", "io16", "wg_fold"):
+            raise MelvocError(f"unknown option {k!r} (mv_options has fuse, io16, wg_fold)")
+        setattr(o, k, int(v))
+    return o
+
+
 class mv_profile_row(C.Structure):
-    _fields_ = [("name", C.c_char * 96), ("launches", C.c_int), ("ms", C.c_double), ("macs_per_frame", C.c_double)]
+    _fields_ = [("name", C.c_char * 192), ("detail", C.c_char * 32), ("launches", C.c_int), ("ms", C.c_double),
+                ("macs_per_frame", C.c_double)]
 
 
 _lib = None
@@ -97,11 +115,14 @@ def lib():
     vp, i32, f32p = C.c_void_p, C.c_int, C.POINTER(C.c_float)
     l.mv_backend.restype = i32
     l.mv_last_error.restype = C.c_char_p
-    l.mv_hifigan_create.argtypes = [C.POINTER(mv_hifigan_cfg), C.POINTER(mv_tensor), i32, i32, i32, C.POINTER(vp)]
+    optp = C.POINTER(mv_options)
+    l.mv_default_options.argtypes = [optp]
+    l.mv_default_options.restype = None
+    l.mv_hifigan_create.argtypes = [C.POINTER(mv_hifigan_cfg), C.POINTER(mv_tensor), i32, i32, i32, optp, C.POINTER(vp)]
     l.mv_hifigan_forward.argtypes = [vp, vp, vp, i32, i32, vp, i32, vp, C.c_size_t, vp]
-    l.mv_waveglow_create.argtypes = [C.POINTER(mv_waveglow_cfg), C.POINTER(mv_tensor), i32, i32, i32, C.POINTER(vp)]
+    l.mv_waveglow_create.argtypes = [C.POINTER(mv_waveglow_cfg), C.POINTER(mv_tensor), i32, i32, i32, optp, C.POINTER(vp)]
     l.mv_waveglow_infer.argtypes = [vp, vp, vp, i32, i32, C.POINTER(vp), i32, C.c_float, vp, i32, vp, C.c_size_t, vp]
-    l.mv_postnet_create.argtypes = [C.POINTER(mv_postnet_cfg), C.POINTER(mv_tensor), i32, i32, i32, C.POINTER(vp)]
+    l.mv_postnet_create.argtypes = [C.POINTER(mv_postnet_cfg), C.POINTER(mv_tensor), i32, i32, i32, optp, C.POINTER(vp)]
     l.mv_postnet_forward.argtypes = [vp, vp, vp, i32, i32, vp, i32, vp, C.c_size_t, vp]
     l.mv_workspace_bytes.argtypes = [vp, i32, i32]
     l.mv_workspace_bytes.restype = C.c_size_t
@@ -202,51 +223,75 @@ class Handle:
         check(lib().mv_profile_begin(self.ptr), "mv_profile_begin")
 
     def profile_end(self):
-        """-> list of dicts {name, launches, ms, macs_per_frame} per kernel instantiation."""
+        """-> list of dicts {name, detail, launches, ms, macs_per_frame}: `name` is the kernel's symbol as rocprofv3
+        prints it, `detail` tells the kinds of launches of one symbol apart."""
         rows = (mv_profile_row * 64)()
         n = C.c_int(0)
         check(lib().mv_profile_end(self.ptr, rows, 64, C.byref(n)), "mv_profile_end")
-        return [dict(name=rows[i].name.decode(), launches=rows[i].launches, ms=rows[i].ms,
-                     macs_per_frame=rows[i].macs_per_frame) for i in range(n.value)]
+        return [dict(name=rows[i].name.decode(), detail=rows[i].detail.decode(), launches=rows[i].launches,
+                     ms=rows[i].ms, macs_per_frame=rows[i].macs_per_frame) for i in range(n.value)]
 
 
-def create_hifigan(cfg, state, device_index: int, precision: int) -> Handle:
+def _optref(options):
+    o = make_options(options)
+    return C.byref(o) if o is not None else None
+
+
+def create_hifigan(cfg, state, device_index: int, precision: int, options=None) -> Handle:
     arr, keep = make_tensors(state)
     c = hifigan_cfg(cfg)
     out = C.c_void_p()
-    check(lib().mv_hifigan_create(C.byref(c), arr, len(keep), int(device_index), int(precision), C.byref(out)),
+    check(lib().mv_hifigan_create(C.byref(c), arr, len(keep), int(device_index), int(precision), _optref(options),
+                                  C.byref(out)),
           "mv_hifigan_create")
     return Handle(out.value, "hifigan")
 
 
-def create_waveglow(cfg, state, device_index: int, precision: int) -> Handle:
+def create_waveglow(cfg, state, device_index: int, precision: int, options=None) -> Handle:
     arr, keep = make_tensors(state)
     c = waveglow_cfg(cfg)
     out = C.c_void_p()
-    check(lib().mv_waveglow_create(C.byref(c), arr, len(keep), int(device_index), int(precision), C.byref(out)),
+    check(lib().mv_waveglow_create(C.byref(c), arr, len(keep), int(device_index), int(precision), _optref(options),
+                                   C.byref(out)),
           "mv_waveglow_create")
     return Handle(out.value, "waveglow")
 
 
-def create_postnet(cfg: mv_postnet_cfg, state, device_index: int, precision: int) -> Handle:
+def create_postnet(cfg: mv_postnet_cfg, state, device_index: int, precision: int, options=None) -> Handle:
     arr, keep = make_tensors(state)
     out = C.c_void_p()
-    check(lib().mv_postnet_create(C.byref(cfg), arr, len(keep), int(device_index), int(precision), C.byref(out)),
+    check(lib().mv_postnet_create(C.byref(cfg), arr, len(keep), int(device_index), int(precision), _optref(options),
+                                  C.byref(out)),
           "mv_postnet_create")
     return Handle(out.value, "postnet")
 
 
+def workspace(cache: dict, dev, nbytes: int):
+    """Scratch tensor for one forward/infer call, cached per (device, current stream): two calls in flight on
+    different streams never share a buffer, and one stream's calls are ordered anyway.  (A handle itself is
+    read-only in forward/infer; only mv_profile_* mutate it.)"""
+    import torch
+
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        cache.pop(key, None)
+        ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=dev)
+        cache[key] = ws
+    return ws
+
+
 def device_lengths(lengths, B, T, dev):
     """int32 [B] frame counts on `dev`.  Host-side lengths are checked here; lengths that already live on the device
-    are clamped into [0, T] there instead (a check would cost a device->host sync in every call, and the kernels only
-    need the bound to stay inside their buffers)."""
+    go through as they are (a check would cost a device->host sync in every call): every kernel of the library
+    clamps the entries it reads into [0, T]."""
     import torch
 
     lengths = torch.as_tensor(lengths)
     if lengths.numel() != B:
         raise RuntimeError("lengths must hold B frame counts in [0, T]")
     if lengths.is_cuda:
-        return lengths.to(device=dev, dtype=torch.int32).clamp(0, T).contiguous()
+        return lengths.to(device=dev, dtype=torch.int32).contiguous()
     lengths = lengths.to(torch.int32)
     if B and (int(lengths.max()) > T or int(lengths.min()) < 0):
         raise RuntimeError("lengths must hold B frame counts in [0, T]")

@@ -118,9 +118,9 @@ def device_mel_bucket(bucket, seed, device, n_mels=80, pad_value=synth.MEL_PAD_V
     return x, torch.tensor(bucket.lengths, dtype=torch.int32)
 
 
-def synthesize_shard(vocoder, mels, lengths=None, rank=0, world=1, device=None, fe_wav=22050, hop=256,
+def synthesize_shard(vocoder, mels, lengths=None, rank=0, world=1, device=None, fe_wav=22050, hop=None,
                      max_batch=32, width=64, max_frames=32 * 1024, keep_audio=True, out="pcm16", pipeline=True,
-                     device_mels=None, d2h=True):
+                     device_mels=None, d2h=True, sink=None):
     """Vocode this rank's share of `mels` (list of [80,T]).  Returns ({utterance index: int16 / float
     numpy waveform}, ShardStats).  `vocoder(mel[B,80,T], lengths=int32[B], out=...) -> [B, hop*T]`.
 
@@ -128,7 +128,14 @@ def synthesize_shard(vocoder, mels, lengths=None, rank=0, world=1, device=None, 
     copy-in stream uploads bucket k, the compute stream vocodes it, and the copy-out stream drains bucket k-1
     into pinned memory (do_syn.py:380-394 does these strictly one after the other).  `device_mels=seed`
     generates the mels on the device instead (config 4); `d2h=False` leaves the audio on the device (then nothing
-    is returned).  The checksum (sum |sample|) is accumulated on the device and read once at the end."""
+    is returned).  The checksum (sum |sample|) is accumulated on the device and read once at the end.
+
+    `sink(i, pcm)`: called once per utterance with a VIEW of the pinned download slot (valid only during the call:
+    write the WAV / hand the bytes on from there) -- with a sink no per-utterance host copy is made, which is what 8
+    ranks sharing one host would otherwise contend on.  `keep_audio` without a sink copies each waveform out of the
+    slot into the returned dict.  `hop` defaults to the vocoder's own samples-per-frame."""
+    if hop is None:
+        hop = int(getattr(vocoder, "hop", 256))
     if lengths is None:
         lengths = [int(m.shape[1]) for m in mels]
     buckets = make_buckets(lengths, max_batch, width, max_frames)
@@ -150,7 +157,9 @@ def synthesize_shard(vocoder, mels, lengths=None, rank=0, world=1, device=None, 
             for b, (i, T) in enumerate(zip(bk.indices, bk.lengths)):
                 a = host[b, : T * hop]
                 stats.checksum += float(np.abs(a.astype(np.float64)).sum())
-                if keep_audio:
+                if sink is not None:
+                    sink(i, a)
+                elif keep_audio:
                     results[i] = a.copy()
             stats.utterances += len(bk.indices)
             stats.frames += bk.cost
@@ -184,10 +193,13 @@ def synthesize_shard(vocoder, mels, lengths=None, rank=0, world=1, device=None, 
 
         def finalize(bk, hb, ev):
             ev.synchronize()
-            if keep_audio:
+            if sink is not None or keep_audio:
                 host = hb.numpy()
                 for b, (i, T) in enumerate(zip(bk.indices, bk.lengths)):
-                    results[i] = host[b, : T * hop].copy()
+                    if sink is not None:
+                        sink(i, host[b, : T * hop])  # a view of the pinned slot: no host copy
+                    else:
+                        results[i] = host[b, : T * hop].copy()
 
         fut = pool_in.submit(prep, 0, mine[0]) if mine else None
         for k, bi in enumerate(mine):

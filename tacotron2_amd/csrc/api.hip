@@ -10,11 +10,32 @@ int launch_convT(const Layer& L, const void* x, long long x_bs, int cin_stride, 
                  int Tmax, hipStream_t stream, Profiler* prof, int in_f16, int out_f16);
 }  // namespace mv
 
+namespace mv {
+int resolve_options(const mv_options* in, mv_options* out) {
+    mv_default_options(out);
+    if (!in) return MV_OK;
+    if (in->fuse < 0 || in->fuse > 2 || in->io16 < 0 || in->io16 > 1 || in->wg_fold < 0 || in->wg_fold > 1) {
+        set_error("mv_options: fuse must be 0..2, io16 and wg_fold 0 or 1 (got %d, %d, %d)", in->fuse, in->io16,
+                  in->wg_fold);
+        return MV_EINVAL;
+    }
+    *out = *in;
+    return MV_OK;
+}
+}  // namespace mv
+
 using namespace mv;
 
 extern "C" {
 
 int mv_backend(void) { return 1; }
+
+void mv_default_options(mv_options* opt) {
+    if (!opt) return;
+    opt->fuse = 2;
+    opt->io16 = 1;
+    opt->wg_fold = 1;
+}
 
 const char* mv_last_error(void) { return last_error_cstr(); }
 
@@ -63,10 +84,11 @@ int mv_profile_end(mv_handle h, mv_profile_row* rows, int max_rows, int* n_rows)
         MV_HIP(hipEventSynchronize(r.e1));
         float ms = 0.f;
         MV_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
-        mv_profile_row& row = acc[r.name];
+        mv_profile_row& row = acc[r.name + "|" + r.detail];
         if (row.launches == 0) {
             memset(&row, 0, sizeof row);
             snprintf(row.name, sizeof row.name, "%s", r.name.c_str());
+            snprintf(row.detail, sizeof row.detail, "%s", r.detail.c_str());
         }
         row.launches += 1;
         row.ms += ms;
@@ -78,11 +100,6 @@ int mv_profile_end(mv_handle h, mv_profile_row* rows, int max_rows, int* n_rows)
     *n_rows = n;
     h->prof.release();
     return MV_OK;
-}
-
-static int test_cfg() {
-    const char* s = getenv("MV_TEST_CFG");
-    return s && *s ? atoi(s) : -1;
 }
 
 int mv_test_conv1d(const float* x, const int32_t* lengths, int B, int L, int Cin, const float* w, const float* bias,
@@ -97,8 +114,7 @@ int mv_test_conv1d(const float* x, const int32_t* lengths, int B, int L, int Cin
     hw.data.assign(w, w + (size_t)Cout * Cin * K);
     if (bias) hb.data.assign(bias, bias + Cout);
     Layer Lr;
-    rc = build_conv1d_layer(&Lr, &hw, bias ? &hb : nullptr, Cin, Cout, K, dilation, Cin, Cout, precision == MV_PREC_BF16,
-                            test_cfg());
+    rc = build_conv1d_layer(&Lr, &hw, bias ? &hb : nullptr, Cin, Cout, K, dilation, Cin, Cout, precision == MV_PREC_BF16);
     if (rc) return rc;
     SrcBind sb{x, (long long)L * Cin, Cin, 1, pre_slope};
     LaunchArgs a;
@@ -128,8 +144,7 @@ int mv_test_conv_transpose1d(const float* x, const int32_t* lengths, int B, int 
     hw.data.assign(w, w + (size_t)Cout * Cin * K);
     if (bias) hb.data.assign(bias, bias + Cout);
     Layer Lr;
-    rc = build_convT_layer(&Lr, &hw, bias ? &hb : nullptr, Cin, Cout, K, stride, Cin, Cout, precision == MV_PREC_BF16,
-                           test_cfg());
+    rc = build_convT_layer(&Lr, &hw, bias ? &hb : nullptr, Cin, Cout, K, stride, Cin, Cout, precision == MV_PREC_BF16, -1);
     if (rc) return rc;
     rc = launch_convT(Lr, x, (long long)L * Cin, Cin, 1, pre_slope, y, (long long)L * stride * Cout, Cout, K, stride,
                       padding, lengths, B, L, (hipStream_t)stream, nullptr, 0, 0);

@@ -62,7 +62,7 @@ struct Layer {
 // Per-launch HIP-event timing, off unless mv_profile_begin() was called on the handle.
 struct Profiler {
     struct Rec {
-        std::string name;
+        std::string name, detail;
         double macs_per_frame;
         hipEvent_t e0, e1;
     };
@@ -70,7 +70,7 @@ struct Profiler {
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
     hipEvent_t get();
-    void begin(hipStream_t s, const std::string& name, double macs_per_frame);
+    void begin(hipStream_t s, const std::string& name, double macs_per_frame, const std::string& detail = "");
     void end(hipStream_t s);
     void release();
 };

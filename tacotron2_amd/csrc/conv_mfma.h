@@ -106,6 +106,14 @@ __device__ __forceinline__ void mma16(f32x4& acc, const u32x4& a, const u32x4& b
 
 __device__ __forceinline__ float lrelu(float x, float slope) { return x >= 0.f ? x : x * slope; }
 
+// Frames of sequence b.  lengths[] comes from the caller of the C ABI: it is clamped into [0, Tmax] where it is read,
+// so an out-of-range entry cannot walk a kernel out of the [B][Tmax * ..] buffers (NULL = every sequence is Tmax long).
+__device__ __forceinline__ int seq_frames(const int32_t* __restrict__ lengths, int b, int Tmax) {
+    if (!lengths) return Tmax;
+    const int v = lengths[b];
+    return v < 0 ? 0 : (v > Tmax ? Tmax : v);
+}
+
 // tanh(t) * sigmoid(s) (waveglow/glow.py:33-40).  fp32 mode: libm.  bf16 mode: (e^2t - 1) / ((e^2t + 1)(1 + e^-s))
 // on the hardware exp2 / rcp (two v_exp_f32 + one v_rcp_f32, ~1 ulp each, against ~3x the instructions for
 // tanhf + expf + an IEEE divide; the gate epilogue was a third of the gated conv's MFMA time).  t is clamped to
@@ -505,7 +513,7 @@ void conv_cl_kernel(const ConvParams p) {
         if (bx >= p.nx) return;
     }
     const int n0 = bx * NT;
-    const int len = p.lengths ? p.lengths[b] : p.Tmax;
+    const int len = seq_frames(p.lengths, b, p.Tmax);
     const int n_ext = len * p.n_rows_per_frame + p.n_extra;
     if (n0 >= n_ext) return;
 

@@ -289,7 +289,7 @@ __device__ __forceinline__ int window_table(int* cum, const int32_t* lengths, in
             const int i = base + (int)threadIdx.x;
             int v = 0;
             if (i < B) {
-                const int len = (lengths ? lengths[i] : Tmax) * rpf;
+                const int len = seq_frames(lengths, i, Tmax) * rpf;
                 v = (len + NT - 1) / NT;
             }
 #pragma unroll
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
     constexpr bool io16x = IO16X;             // float16 windows come and go through LDS, next one prefetched
 
     int b = find_seq(cum_s, p.B, v);
-    int len = (p.lengths ? p.lengths[b] : p.Tmax) * p.rows_per_frame;
+    int len = seq_frames(p.lengths, b, p.Tmax) * p.rows_per_frame;
     int t0 = (v - cum_s[b]) * p.NT - p.H;     // global row of window row 0
     if constexpr (io16x) {  // the block's first window arrives synchronously, every later one is prefetched
         u32x4 raw[WL::PER], rawa[AL::PER];
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
         int bn = 0, lenn = 0, t0n = 0;
         if (has_next) {
             bn = find_seq(cum_s, p.B, vn);
-            lenn = (p.lengths ? p.lengths[bn] : p.Tmax) * p.rows_per_frame;
+            lenn = seq_frames(p.lengths, bn, p.Tmax) * p.rows_per_frame;
             t0n = (vn - cum_s[bn]) * p.NT - p.H;
         }
 
@@ -743,7 +743,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
     constexpr int FRAG_TN = 16 * RS;
 
     int b = find_seq(cum_s, p.B, v);
-    int len = (p.lengths ? p.lengths[b] : p.Tmax) * p.rows_per_frame;
+    int len = seq_frames(p.lengths, b, p.Tmax) * p.rows_per_frame;
     int out0 = (v - cum_s[b]) * p.NT;
     if constexpr (IO16) {  // the block's first window arrives synchronously, every later one is prefetched
         u32x4 raw[WL::PER], rawa[AL::PER];
@@ -778,7 +778,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
         int bn = 0, lenn = 0, out0n = 0;
         if (has_next) {
             bn = find_seq(cum_s, p.B, vn);
-            lenn = (p.lengths ? p.lengths[bn] : p.Tmax) * p.rows_per_frame;
+            lenn = seq_frames(p.lengths, bn, p.Tmax) * p.rows_per_frame;
             out0n = (vn - cum_s[bn]) * p.NT;
         }
         for (int j = 0; j < p.nrb; ++j) {

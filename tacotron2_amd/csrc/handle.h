@@ -6,6 +6,7 @@ struct mv_handle_s {
     int kind = 0;  // 1 = HiFi-GAN generator, 2 = WaveGlow, 3 = Tacotron2 Postnet
     int device = 0;
     int precision = MV_PREC_FP32;
+    mv_options opt = {2, 1, 1};  // see mv_default_options
     mv::Profiler prof;
     virtual ~mv_handle_s() { prof.release(); }
     virtual size_t workspace_bytes(int B, int Tmax) const = 0;
@@ -14,6 +15,9 @@ struct mv_handle_s {
 };
 
 namespace mv {
+
+// options of a create call: the defaults, overridden by what the caller passed; MV_EINVAL on a value out of range
+int resolve_options(const mv_options* in, mv_options* out);
 
 // small kernels shared by both vocoders (small_kernels.hip)
 int launch_to_channels_last(const float* x, int B, int C, int T, float* y, int Cp, hipStream_t s);

@@ -37,44 +37,34 @@ namespace mv {
 // ---- fused ResBlock launches (bf16 mode) ------------------------------------------------------
 typedef void (*FusedKernel)(const FusedRbParams);
 struct FusedCfg {
-    int C, W, threads, npair;
-    FusedKernel k;
-    const char* name;
-    FusedKernel k16;  // float16-IO variant, null if there is none
-    FusedKernel k16_one;  // ... specialised for one pair per launch, null if there is none
+    int C, WM, WN, TN, npair;
+    FusedKernel k;        // float32 window IO
+    FusedKernel k16;      // float16 window IO through LDS
+    FusedKernel k16_one;  // ... specialised for one pair per launch
+    int W() const { return 16 * TN * WN; }
+    int threads() const { return 64 * WM * WN; }
 };
-//                         C   WM WN TN [IO16X [ONE]]
+// 8 waves (two per SIMD): the second wave hides LDS / L2 latency and the epilogue phases
+#define MV_FUSED_CFG(C, WM, WN, TN, NPAIR)                                                  \
+    {                                                                                       \
+        C, WM, WN, TN, NPAIR, fused_rb_kernel<C, WM, WN, TN>, fused_rb_kernel<C, WM, WN, TN, true>, \
+            fused_rb_kernel<C, WM, WN, TN, true, true>                                      \
+    }
 static const FusedCfg kFused[] = {
-    // 8 waves (two per SIMD): the second wave hides LDS / L2 latency and the epilogue phases
-    {32, 768, 512, 3, fused_rb_kernel<32, 1, 8, 6>, "fused_rb_kernel<C32,WM1,WN8,TN6,xreg>",
-     fused_rb_kernel<32, 1, 8, 6, true>, fused_rb_kernel<32, 1, 8, 6, true, true>},
-    {64, 448, 512, 3, fused_rb_kernel<64, 2, 4, 7>, "fused_rb_kernel<C64,WM2,WN4,TN7,xreg>",
-     fused_rb_kernel<64, 2, 4, 7, true>, fused_rb_kernel<64, 2, 4, 7, true, true>},
-    {128, 224, 512, 3, fused_rb_kernel<128, 4, 2, 7>, "fused_rb_kernel<C128,WM4,WN2,TN7,xreg>",
-     fused_rb_kernel<128, 4, 2, 7, true>, fused_rb_kernel<128, 4, 2, 7, true, true>},
-    {256, 112, 512, 1, fused_rb_kernel<256, 8, 1, 7>, "fused_rb_kernel<C256,WM8,WN1,TN7,xreg>",
-     fused_rb_kernel<256, 8, 1, 7, true>, fused_rb_kernel<256, 8, 1, 7, true, true>},
-    // 4-wave variants, kept for A/B runs (MV_FUSE bit mask: 2 -> C32, 4 -> C64, 8 -> C128)
-    {32, 768, 256, 3, fused_rb_kernel<32, 1, 4, 12>, "fused_rb_kernel<C32,WM1,WN4,TN12,xreg>", nullptr, nullptr},
-    {64, 320, 256, 3, fused_rb_kernel<64, 2, 2, 10>, "fused_rb_kernel<C64,WM2,WN2,TN10,xreg>", nullptr, nullptr},
-    {128, 96, 256, 3, fused_rb_kernel<128, 4, 1, 6>, "fused_rb_kernel<C128,WM4,WN1,TN6,xreg>",
-     fused_rb_kernel<128, 4, 1, 6, true>, nullptr},
+    MV_FUSED_CFG(32, 1, 8, 6, 3),
+    MV_FUSED_CFG(64, 2, 4, 7, 3),
+    MV_FUSED_CFG(128, 4, 2, 7, 3),
+    MV_FUSED_CFG(256, 8, 1, 7, 1),
 };
 
-static int env_or(const char* name, int dflt) {
-    const char* s = getenv(name);
-    return s && *s ? atoi(s) : dflt;
-}
+// launch-shape thresholds (measured on the bench batch)
+constexpr int kWholeMinPct = 80;  // a whole ResBlock in one launch while NT / W is at least this
+constexpr int kPairMinPct = 60;   // a lone (conv, conv) pair below this recomputes too much halo: layer by layer
+constexpr int kStageMinPct = 55;  // likewise for a whole-stage launch
 
 static const FusedCfg* fused_cfg_for(int Cp) {
-    static const int mode = env_or("MV_FUSE", 1);
-    if (!mode) return nullptr;
-    for (const FusedCfg& f : kFused) {
-        if (f.C != Cp) continue;
-        const bool want4 = (mode & (Cp == 32 ? 2 : Cp == 64 ? 4 : Cp == 128 ? 8 : 0)) != 0;
-        if (Cp == 256 && (mode & 16)) return nullptr;
-        if ((f.threads == 256) == want4) return &f;
-    }
+    for (const FusedCfg& f : kFused)
+        if (f.C == Cp) return &f;
     return nullptr;
 }
 
@@ -85,30 +75,31 @@ static bool fuse_whole(const FusedCfg& fc, int K, const int* dils, int io16) {
     int H = 0;
     for (int m = 0; m < 3; ++m) H += (K - 1) / 2 * (dils[m] + 1);
     if (io16 && fc.k16 && dils[0] * (K - 1) / 2 <= kMaxApron) H -= dils[0] * (K - 1) / 2;  // see launch_fused_rb
-    static const int pct = env_or("MV_WHOLE_MIN_PCT", 80);  // NT / W at least this
-    return (fc.W - 2 * H) * 100 >= fc.W * pct;
+    return (fc.W() - 2 * H) * 100 >= fc.W() * kWholeMinPct;
 }
 
 // whole-stage launches (all ResBlocks + MRF mean [+ conv_post]) for the HBM-bound low-channel stages
 typedef void (*StageKernel)(const FusedStageParams);
 struct StageCfg {
-    int C, W, threads;
+    int C, WM, WN, TN;
     StageKernel k[2][2];  // [io16][with conv_post]
-    const char* name;
+    int W() const { return 16 * TN * WN; }
+    int threads() const { return 64 * WM * WN; }
 };
 static const StageCfg kStage[] = {
-#define MV_STAGE_VARIANTS(C, WM, WN, TN)                                                               \
-    {                                                                                                  \
-        {fused_stage_kernel<C, WM, WN, TN, false, false>, fused_stage_kernel<C, WM, WN, TN, false, true>}, \
-        {fused_stage_kernel<C, WM, WN, TN, true, false>, fused_stage_kernel<C, WM, WN, TN, true, true>},   \
+#define MV_STAGE_CFG(C, WM, WN, TN)                                                                        \
+    {                                                                                                      \
+        C, WM, WN, TN, {                                                                                   \
+            {fused_stage_kernel<C, WM, WN, TN, false, false>, fused_stage_kernel<C, WM, WN, TN, false, true>}, \
+                {fused_stage_kernel<C, WM, WN, TN, true, false>, fused_stage_kernel<C, WM, WN, TN, true, true>}, \
+        }                                                                                                  \
     }
-    {32, 768, 512, MV_STAGE_VARIANTS(32, 1, 8, 6), "fused_stage_kernel<C32,WM1,WN8,TN6>"},
-    {64, 448, 512, MV_STAGE_VARIANTS(64, 2, 4, 7), "fused_stage_kernel<C64,WM2,WN4,TN7>"},
+    MV_STAGE_CFG(32, 1, 8, 6),
+    MV_STAGE_CFG(64, 2, 4, 7),
 };
 static const StageCfg* stage_cfg_for(int Cp) {
-    static const int mode = env_or("MV_STAGE", 3);  // bit 0: C32, bit 1: C64
     for (const StageCfg& f : kStage)
-        if (f.C == Cp && (mode & (Cp == 32 ? 1 : 2))) return &f;
+        if (f.C == Cp) return &f;
     return nullptr;
 }
 
@@ -195,7 +186,7 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const void* __restrict__
     const long long L = (long long)Tmax * hop;
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= L) return;
-    const long long len = (long long)(lengths ? lengths[b] : Tmax) * hop;
+    const long long len = (long long)seq_frames(lengths, b, Tmax) * hop;
     float y = 0.f;
     if (t < len) {
         const long long xoff = (long long)b * batch_stride;
@@ -278,14 +269,6 @@ int build_convT_layer(Layer* L, const HostTensor* w, const HostTensor* b, int Ci
     std::vector<float> bias((size_t)u * cout_pad, 0.f);
     for (int p = 0; p < u; ++p)
         for (int i = 0; i < Cout; ++i) bias[(size_t)p * cout_pad + i] = b ? b->data[i] : 0.f;
-    if (force_cfg < 0 && bf16) {  // the low-channel upsamplers are HBM-bound: their tile shape is tuned on its own
-        const int M = u * cout_pad;
-        static const int c128 = env_or("MV_CFG_UPS_M128", -1), c64 = env_or("MV_CFG_UPS_M64", -1);
-        static const int cbig = env_or("MV_CFG_UPS_M256", -1);
-        if (M == 128) force_cfg = c128;
-        if (M == 64) force_cfg = c64;
-        if (M % 256 == 0) force_cfg = cbig;
-    }
     return build_layer(L, {s}, u * cout_pad, bias, bf16, EPI_LINEAR, force_cfg);
 }
 
@@ -455,29 +438,26 @@ static int launch_fused_rb(const FusedCfg& fc, const RbPair* pairs, int m0, int 
         macs += pr.c1.alg_macs_per_n + pr.c2.alg_macs_per_n;
     }
     p.H = H;
-    p.NT = fc.W - 2 * H;
+    p.NT = fc.W() - 2 * H;
     p.guardA = gA;
     p.guardY = pad2;
     const int RS = fc.C * 2 + kLdsRowPad;
-    const size_t lds = (size_t)(2 * fc.W + 2 * gA + 2 * pad2) * RS + (size_t)2 * npair * fc.C * 4;  // tiles + biases
-    static const int pair_pct = env_or("MV_PAIR_MIN_PCT", 60);  // below this the halo recompute costs too much
-    if (p.NT < 16 || lds > kFusedMaxLds || p.NT * 100 < fc.W * pair_pct || B > kMaxSeq) return MV_EUNSUPPORTED;
+    const size_t lds = (size_t)(2 * fc.W() + 2 * gA + 2 * pad2) * RS + (size_t)2 * npair * fc.C * 4;  // tiles + biases
+    if (p.NT < 16 || lds > kFusedMaxLds || p.NT * 100 < fc.W() * kPairMinPct || B > kMaxSeq) return MV_EUNSUPPORTED;
     const long long rows = (long long)Tmax * rpf;
     // persistent blocks, one per CU (LDS allows no more), each walking every gridDim.x-th existing window
     const long long vmax = ((rows + p.NT - 1) / p.NT) * B;
-    // 4-wave blocks whose tiles fit half the LDS run two to a CU: one block's epilogue / barrier / window IO phases
-    // overlap the other's K loops
-    const int per_cu = fc.threads <= 256 && lds + 4608 <= 80 * 1024 ? 2 : 1;
-    dim3 grid((unsigned)std::min<long long>(vmax, (long long)per_cu * cu_count()));
+    dim3 grid((unsigned)std::min<long long>(vmax, (long long)cu_count()));
+    const bool one = io16 && npair == 1;
+    FusedKernel kern = one ? fc.k16_one : io16 ? fc.k16 : fc.k;
     if (prof) {
-        char nm[128];
-        snprintf(nm, sizeof nm, "%s k=%d", fc.name, K);
-        prof->begin(stream, nm, macs * rpf);
+        char nm[128], dt[32];  // the symbol as rocprofv3 prints it + which of its launches
+        snprintf(nm, sizeof nm, "void mv::fused_rb_kernel<%d, %d, %d, %d, %s, %s>(mv::FusedRbParams)", fc.C, fc.WM, fc.WN,
+                 fc.TN, io16 ? "true" : "false", one ? "true" : "false");
+        snprintf(dt, sizeof dt, "k=%d", K);
+        prof->begin(stream, nm, macs * rpf, dt);
     }
-    static const int one_on = env_or("MV_RB_ONE", 1);
-    FusedKernel kern = io16 && fc.k16 ? fc.k16 : fc.k;
-    if (io16 && npair == 1 && fc.k16_one && one_on) kern = fc.k16_one;
-    hipLaunchKernelGGL(kern, grid, dim3(fc.threads), lds, stream, p);
+    hipLaunchKernelGGL(kern, grid, dim3(fc.threads()), lds, stream, p);
     if (prof) prof->end(stream);
     MV_HIP(hipGetLastError());
     return MV_OK;
@@ -540,22 +520,24 @@ static int launch_fused_stage(const StageCfg& sc, const HifiganHandle* h, int i,
         macs += (double)h->C[h->nstage] * 7;
     }
     p.H = H;
-    p.NT = sc.W - 2 * H;
+    p.NT = sc.W() - 2 * H;
     p.guardA = gA;
     p.guardY = gY;
     const int RS = sc.C * 2 + kLdsRowPad;
-    const size_t lds = (size_t)(2 * sc.W + 2 * gA + 2 * gY) * RS + (size_t)6 * nrb * sc.C * 4;  // + biases
-    static const int min_pct = env_or("MV_STAGE_MIN_PCT", 55);
-    if (lds > kFusedMaxLds || p.NT * 100 < sc.W * min_pct || B > kMaxSeq) return MV_EUNSUPPORTED;
+    const size_t lds = (size_t)(2 * sc.W() + 2 * gA + 2 * gY) * RS + (size_t)6 * nrb * sc.C * 4;  // + biases
+    if (lds > kFusedMaxLds || p.NT * 100 < sc.W() * kStageMinPct || B > kMaxSeq) return MV_EUNSUPPORTED;
     const long long rows = (long long)Tmax * rpf;
     const long long vmax = ((rows + p.NT - 1) / p.NT) * B;
     dim3 grid((unsigned)std::min<long long>(vmax, cu_count()));
     // the persistent blocks visit only windows that exist; the waveform past a sequence's end is zero
     if (wav) MV_HIP(hipMemsetAsync(wav, 0, (size_t)B * rows * (out_format == MV_OUT_PCM16 ? 2 : 4), stream));
-    if (prof)
-        prof->begin(stream, std::string(sc.name) + (wav ? "+conv_post" : nrb < c.num_kernels ? " first ResBlocks" : ""),
-                    macs * rpf);
-    hipLaunchKernelGGL(sc.k[io16 ? 1 : 0][wav ? 1 : 0], grid, dim3(sc.threads), lds, stream, p);
+    if (prof) {
+        char nm[128];
+        snprintf(nm, sizeof nm, "void mv::fused_stage_kernel<%d, %d, %d, %d, %s, %s>(mv::FusedStageParams)", sc.C, sc.WM,
+                 sc.WN, sc.TN, io16 ? "true" : "false", wav ? "true" : "false");
+        prof->begin(stream, nm, macs * rpf, wav ? "+conv_post" : nrb < c.num_kernels ? "first ResBlocks" : "");
+    }
+    hipLaunchKernelGGL(sc.k[io16 ? 1 : 0][wav ? 1 : 0], grid, dim3(sc.threads()), lds, stream, p);
     if (prof) prof->end(stream);
     MV_HIP(hipGetLastError());
     return MV_OK;
@@ -572,8 +554,7 @@ static int hifigan_forward(HifiganHandle* h, const float* mel, const int32_t* le
     int rc;
     Profiler* prof = h->prof.on ? &h->prof : nullptr;
     // bf16 mode: activations between kernels are float16 (see ld4/st4 in conv_mfma.h); fp32 mode: float32
-    static const int io16_env = env_or("MV_IO16", 1);
-    const int io16 = h->precision == MV_PREC_BF16 ? io16_env : 0;
+    const int io16 = h->precision == MV_PREC_BF16 ? h->opt.io16 : 0;
     const size_t bt = (size_t)B * Tmax;
     char* ws = (char*)workspace;
     float* X0 = (float*)ws;
@@ -612,16 +593,15 @@ static int hifigan_forward(HifiganHandle* h, const float* mel, const int32_t* le
         if ((rc = launch_convT(h->ups[i], cur_in, bs_in, Cin_p, rpf, 0.1f, A, bs, Cp, K, u, (K - u) / 2, lengths, B,
                                Tmax, stream, prof, io16, io16)))
             return rc;
-        const FusedCfg* fc = h->precision == MV_PREC_BF16 ? fused_cfg_for(Cp) : nullptr;
-        const StageCfg* sc = h->precision == MV_PREC_BF16 ? stage_cfg_for(Cp) : nullptr;
+        const FusedCfg* fc = h->precision == MV_PREC_BF16 && h->opt.fuse >= 1 ? fused_cfg_for(Cp) : nullptr;
+        const StageCfg* sc = h->precision == MV_PREC_BF16 && h->opt.fuse >= 2 ? stage_cfg_for(Cp) : nullptr;
         int j0 = 0;  // ResBlocks [0, j0) are done by a stage launch
         if (sc) {
             const bool last = i == h->nstage - 1;
             // The window of a stage launch pays the halo of its widest ResBlock for all of them.  Where HBM is not
             // the bound (C64), the widest (last) one runs pair by pair afterwards with each pair's own, smaller halo.
-            static const int split64 = env_or("MV_STAGE_SPLIT_C64", 1);
             int nrb = c.num_kernels;
-            if (!last && Cp == 64 && split64 && fc && nrb == 3 && io16) nrb = 2;
+            if (!last && Cp == 64 && fc && nrb == 3 && io16) nrb = 2;
             rc = launch_fused_stage(*sc, h, i, nrb, A, ACC, bs, rpf_out, last ? wav : nullptr, out_format, lengths, B,
                                     Tmax, stream, prof, io16);
             if (rc == MV_OK) {
@@ -707,7 +687,7 @@ using namespace mv;
 extern "C" {
 
 int mv_hifigan_create(const mv_hifigan_cfg* cfg, const mv_tensor* weights, int n_weights, int device, int precision,
-                      mv_handle* out) {
+                      const mv_options* options, mv_handle* out) {
     if (!cfg || !weights || !out || n_weights <= 0) {
         set_error("mv_hifigan_create: null argument");
         return MV_EINVAL;
@@ -722,12 +702,15 @@ int mv_hifigan_create(const mv_hifigan_cfg* cfg, const mv_tensor* weights, int n
         set_error("mv_hifigan_create: bad config");
         return MV_EINVAL;
     }
+    mv_options opt;
+    int rc = resolve_options(options, &opt);
+    if (rc) return rc;
     DeviceGuard g(device);
     if (!g.ok) {
         set_error("mv_hifigan_create: cannot select HIP device %d", device);
         return MV_EHIP;
     }
-    int rc = init_kernel_attributes();
+    rc = init_kernel_attributes();
     if (rc) return rc;
     if ((rc = init_fused_attributes())) return rc;
     WeightMap W;
@@ -736,6 +719,7 @@ int mv_hifigan_create(const mv_hifigan_cfg* cfg, const mv_tensor* weights, int n
     h->kind = 1;
     h->device = device;
     h->precision = precision;
+    h->opt = opt;
     h->cfg = *cfg;
     if ((rc = hifigan_build(h, W))) {
         delete h;

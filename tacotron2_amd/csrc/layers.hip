@@ -32,16 +32,12 @@ const TileCfg kTileCfgs[] = {
 };
 const int kNumTileCfgs = sizeof(kTileCfgs) / sizeof(kTileCfgs[0]);
 
-static int env_int(const char* name, int dflt) {
-    const char* s = getenv(name);
-    return s && *s ? atoi(s) : dflt;
-}
-
+// tile shape by output-channel count (measured best of kTileCfgs per class on the two vocoders' layers)
 static int default_cfg(int M) {
-    if (M % 256 == 0) return env_int("MV_CFG_M256", 0);
-    if (M % 128 == 0) return env_int("MV_CFG_M128", 2);
-    if (M % 64 == 0) return env_int("MV_CFG_M64", 3);
-    return env_int("MV_CFG_M32", 4);
+    if (M % 256 == 0) return 0;
+    if (M % 128 == 0) return 2;
+    if (M % 64 == 0) return 3;
+    return 4;
 }
 
 static inline uint16_t f2bf(float x) {
@@ -71,9 +67,7 @@ int build_layer(Layer* L, const std::vector<SrcSpec>& srcs, int M, const std::ve
     }
     // 4-wave tiles: two blocks per CU; the 8-wave tile has the CU to itself
     const bool big = tc.WM * tc.WN >= 8;
-    const size_t lds_budget =
-        (size_t)env_int(bf16 ? (big ? "MV_LDS_BUDGET_KB_BIG" : "MV_LDS_BUDGET_KB") : "MV_LDS_BUDGET_KB_FP32",
-                        bf16 && !big ? 72 : 128) * 1024;  // 4-wave tiles: two blocks per CU (2 x 72 KB of 160)
+    const size_t lds_budget = (size_t)(bf16 && !big ? 72 : 128) * 1024;  // 4-wave tiles: two blocks per CU (2 x 72 KB of 160)
     L->npass = 0;
     L->lds_bytes = 0;
     L->steps_total = 0;
@@ -212,9 +206,9 @@ hipEvent_t Profiler::get() {
     (void)hipEventCreate(&e);
     return e;
 }
-void Profiler::begin(hipStream_t s, const std::string& name, double macs_per_frame) {
+void Profiler::begin(hipStream_t s, const std::string& name, double macs_per_frame, const std::string& detail) {
     if (!on) return;
-    Rec r{name, macs_per_frame, get(), get()};
+    Rec r{name, detail, macs_per_frame, get(), get()};
     (void)hipEventRecord(r.e0, s);
     recs.push_back(r);
 }
@@ -237,8 +231,9 @@ void Profiler::release() {
 std::string layer_kernel_name(const Layer& L) {
     const TileCfg& tc = kTileCfgs[L.cfg];
     char buf[128];
-    snprintf(buf, sizeof buf, "conv_cl_kernel<%s,TM%d,TN%d,WM%d,WN%d,%s>", L.bf16 ? "bf16" : "fp32", tc.TM, tc.TN, tc.WM,
-             tc.WN, L.epi == EPI_GATE ? "gate" : "linear");
+    // the symbol as rocprofv3 prints it
+    snprintf(buf, sizeof buf, "void mv::conv_cl_kernel<%s, %d, %d, %d, %d, %d>(mv::ConvParams)",
+             L.bf16 ? "true" : "false", tc.TM, tc.TN, tc.WM, tc.WN, L.epi);
     return buf;
 }
 
@@ -287,7 +282,6 @@ int launch_layer(const Layer& L, const SrcBind* srcs, int nsrc, const LaunchArgs
     p.resid_batch_stride = a.resid_batch_stride;
     p.div = a.div;
     p.act = a.act;
-    static const int epi_lds_on = env_int("MV_EPI_LDS", 1);
     // the coalescing epilogue (conv_cl_kernel) wants 8-element units that never straddle a validity bound, a
     // block's M range on one side of the split, and a residual typed and laid out like out[0]
     const int mo = L.epi == EPI_GATE ? tc.MT() / 2 : tc.MT();
@@ -295,7 +289,7 @@ int launch_layer(const Layer& L, const SrcBind* srcs, int nsrc, const LaunchArgs
     auto unit_ok = [&](const ConvOut& o) {
         return o.row_stride % 8 == 0 && o.off % 8 == 0 && o.valid_per_frame % 8 == 0 && o.batch_stride % 8 == 0;
     };
-    p.epi_lds = epi_lds_on && L.bf16 && unit_ok(a.out[0]) && (!two || (a.split % mo == 0 && unit_ok(a.out[1]))) &&
+    p.epi_lds = L.bf16 && unit_ok(a.out[0]) && (!two || (a.split % mo == 0 && unit_ok(a.out[1]))) &&
                 (L.epi == EPI_LINEAR || !two) && a.resid_batch_stride % 8 == 0;
     // bfloat16 storage (dtype code 2) is for tensors that are only ever MFMA operands: a plain copy on the way in,
     // a plain store on the way out
@@ -316,15 +310,13 @@ int launch_layer(const Layer& L, const SrcBind* srcs, int nsrc, const LaunchArgs
     dim3 grid(nx, ny, (unsigned)a.B);
     // M-blocks of a row tile on one XCD (conv_cl_kernel) -- when the activations are the big operand.  The price is
     // that every XCD's L2 then cycles through all ny weight slices instead of sitting on one, so layers with few
-    // rows and many output channels (conv_pre, the first upsampler) keep the natural order.  MV_XCD_SWIZZLE:
-    // 0 never, 1 by this estimate, 2 always.
-    static const int xcd_on = env_int("MV_XCD_SWIZZLE", 1);
+    // rows and many output channels (conv_pre, the first upsampler) keep the natural order.
     double act_row_bytes = 0;
     for (int i = 0; i < L.npass; ++i)
         if (L.pass[i].tap0 == 0) act_row_bytes += (double)L.pass[i].cb * (L.bf16 ? 2 : 4);
     const double act_bytes = (double)a.B * (double)n_max * act_row_bytes;
     const double w_bytes = (double)L.M * L.steps_total * (L.bf16 ? 64 : 64);  // 16 rows x 1 KiB per (M tile, K step)
-    if (ny > 1 && (xcd_on == 2 || (xcd_on == 1 && act_bytes >= 8.0 * w_bytes))) {
+    if (ny > 1 && act_bytes >= 8.0 * w_bytes) {
         p.xcd_ny = (int)ny;
         p.nx = (int)nx;
         grid = dim3((nx + 7) / 8 * 8 * ny, 1, (unsigned)a.B);

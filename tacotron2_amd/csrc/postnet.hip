@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void from_channels_last_kernel(const float* __
     const int b = blockIdx.z;
     const int t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-    const int len = lengths ? lengths[b] : T;
+    const int len = seq_frames(lengths, b, T);
     for (int i = ty; i < 32; i += 8) {
         const int t = t0 + i, c = c0 + tx;
         tile[i][tx] = (t < len && c < Cp) ? x[((long long)b * T + t) * Cp + c] : 0.f;
@@ -161,7 +161,7 @@ using namespace mv;
 extern "C" {
 
 int mv_postnet_create(const mv_postnet_cfg* cfg, const mv_tensor* weights, int n_weights, int device, int precision,
-                      mv_handle* out) {
+                      const mv_options* options, mv_handle* out) {
     if (!cfg || !weights || !out || n_weights <= 0) {
         set_error("mv_postnet_create: null argument");
         return MV_EINVAL;
@@ -176,12 +176,15 @@ int mv_postnet_create(const mv_postnet_cfg* cfg, const mv_tensor* weights, int n
         set_error("mv_postnet_create: bad config");
         return MV_EINVAL;
     }
+    mv_options opt;
+    int rc = resolve_options(options, &opt);
+    if (rc) return rc;
     DeviceGuard g(device);
     if (!g.ok) {
         set_error("mv_postnet_create: cannot select HIP device %d", device);
         return MV_EHIP;
     }
-    int rc = init_kernel_attributes();
+    rc = init_kernel_attributes();
     if (rc) return rc;
     WeightMap W;
     if ((rc = W.load(weights, n_weights))) return rc;
@@ -189,6 +192,7 @@ int mv_postnet_create(const mv_postnet_cfg* cfg, const mv_tensor* weights, int n
     h->kind = 3;
     h->device = device;
     h->precision = precision;
+    h->opt = opt;
     h->cfg = *cfg;
     if ((rc = postnet_build(h, W))) {
         delete h;

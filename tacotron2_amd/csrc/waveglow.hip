@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void wg_tail_kernel(const void* __restrict__ s
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int part = lane >> 4;
     const int l = (blockIdx.x * 4 + wave) * 16 + (lane & 15);
-    const int len = (lengths ? lengths[b] : Tmax) * steps_per_frame;
+    const int len = seq_frames(lengths, b, Tmax) * steps_per_frame;
     const bool live = l < L;
     const bool valid = live && l < len;
     float acc[8];
@@ -299,11 +299,6 @@ static void invert_small(const float* A, int n, float* out) {
     }
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) out[i * n + j] = (float)a[i * 2 * n + n + j];
-}
-
-static int env_or_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v && *v ? atoi(v) : dflt;
 }
 
 static int expect(const HostTensor* t, std::initializer_list<int64_t> shape, const char* name) {
@@ -417,7 +412,7 @@ static int waveglow_build(WaveglowHandle* h, WeightMap& W) {
         // matrix applied on the VALU in fp32 -- and the MFMA layer keeps its residual half only.  Halves the res_skip
         // FLOPs and drops the skip tensor's read-modify-write; the values differ from the reference order of
         // operations by fp32 rounding only (the products are formed in double here).
-        const bool fold = bf16 && env_or_int("MV_WG_FOLD", 1) != 0;
+        const bool fold = bf16 && h->opt.wg_fold != 0;
         h->fold = fold;
         std::vector<double> fold_bias(2 * n_half, 0.0);
         std::vector<float> fold_all(fold ? (size_t)nl * 2 * n_half * h->Cp : 0, 0.f);
@@ -460,7 +455,7 @@ static int waveglow_build(WaveglowHandle* h, WeightMap& W) {
             for (int m = 0; m < 2 * C; ++m) bias[m] = ib->data[orig(m)] + cbd[orig(m)];
             // bf16: 256 x 128 tiles (a weight fragment feeds 8 MFMAs instead of 4: the L1 weight stream paces
             // the 256 x 64 tile)
-            const int wide = bf16 && (2 * C) % 256 == 0 ? env_or_int("MV_WG_CFG", 1) : -1;
+            const int wide = bf16 && (2 * C) % 256 == 0 ? 1 : -1;
             if ((rc = build_layer(&f.in_layers[i], {sh, sc}, 2 * C, bias, bf16, EPI_GATE, wide))) return rc;
             f.in_layers[i].alg_macs_per_n = (double)2 * C * C * ks + (double)2 * C * h->ncond;
 
@@ -478,7 +473,7 @@ static int waveglow_build(WaveglowHandle* h, WeightMap& W) {
             sa.dil = 1;
             sa.pad_left = 0;
             sa.w = [=](int m, int, int ci) -> float { return ci < C ? rwd[(size_t)m * C + ci] : 0.f; };
-            const int rwide = bf16 && rsC % 256 == 0 ? env_or_int("MV_WG_CFG", 1) : -1;
+            const int rwide = bf16 && rsC % 256 == 0 ? 1 : -1;
             if (!fold) {
                 if ((rc = build_layer(&f.res_skip[i], {sa}, rsC, rb->data, bf16, EPI_LINEAR, rwide))) return rc;
                 f.res_skip[i].alg_macs_per_n = (double)rsC * C;
@@ -496,7 +491,7 @@ static int waveglow_build(WaveglowHandle* h, WeightMap& W) {
                 }
                 if (i < nl - 1) {
                     std::vector<float> rbias(rb->data.begin(), rb->data.begin() + C);
-                    const int cfg = C % 256 == 0 ? env_or_int("MV_WG_RES_CFG", 0) : -1;
+                    const int cfg = C % 256 == 0 ? 0 : -1;
                     if ((rc = build_layer(&f.res_only[i], {sa}, C, rbias, true, EPI_LINEAR, cfg))) return rc;
                     f.res_only[i].alg_macs_per_n = (double)C * C;
                 }
@@ -555,19 +550,16 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
     ws += WaveglowHandle::al(bl * Cp * 4);
     void* ACTS = ws;
     ws += WaveglowHandle::al(bl * Cp * 4);
-    static const int io16_env = env_or_int("MV_WG_IO16", 0);  // measured slower than float32 storage at B = 1 (staging converts more than it saves)
-    const int io16 = h->precision == MV_PREC_BF16 && io16_env ? 1 : 0;
+    const int io16 = 0;  // H / SKIP stay float32 (float16 storage measured slower at B = 1: staging converts more than it saves)
     // The gated activations and the upsampled mel are read as MFMA operands only: in bf16 mode they are stored as
     // bfloat16, rounded where they are produced instead of where they are staged -- the same values reach the
     // MFMAs, at half the bytes and with plain 16-byte copies into LDS.
-    static const int opbf_env = env_or_int("MV_WG_OPERAND_BF16", 1);
-    const int opd = h->precision == MV_PREC_BF16 && opbf_env ? 2 : io16;
+    const int opd = h->precision == MV_PREC_BF16 && h->opt.io16 ? 2 : io16;
     // Likewise the residual stream H: it accumulates in float32, and every kernel that updates it also leaves a
     // bfloat16 copy (in the unused half of the ACTS buffer) for the next gated conv to stage by plain copies.
     unsigned short* Hb = opd == 2 ? (unsigned short*)((char*)ACTS + WaveglowHandle::al(bl * Cp * 2)) : nullptr;
     // one fold launch per flow over all its layers' activations (needs them all kept: bf16 operand storage)
-    static const int fold_batch_env = env_or_int("MV_WG_FOLD_BATCH", 1);
-    const bool fold_batch = h->fold && opd == 2 && fold_batch_env;
+    const bool fold_batch = h->fold && opd == 2;
     const size_t slot = WaveglowHandle::al(bl * Cp * 2);
     char* ACTS_REST = ws;  // slots 1 .. n_layers-1
     if (h->fold) ws += (size_t)(nl - 1) * slot;
@@ -629,7 +621,7 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
                 // (rows past a sequence's end hold stale activations: their sums are never read, wg_tail masks them)
                 if (!fold_batch || i == nl - 1) {
                     const int nfold = fold_batch ? nl : 1;
-                    if (prof) prof->begin(stream, "wg_skipfold_kernel", (double)nfold * nout * h->C * spf);
+                    if (prof) prof->begin(stream, "mv::wg_skipfold_kernel(void const*, void const*, long long, int, int, int, float const*, int, long long, float*, int)", (double)nfold * nout * h->C * spf);
                     hipLaunchKernelGGL(wg_skipfold_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256),
                                        (size_t)nout * Cp * 4, stream, (const void*)ACTS, (const void*)ACTS_REST,
                                        (long long)(slot / 2), nfold, opd, Cp,
@@ -687,7 +679,7 @@ using namespace mv;
 extern "C" {
 
 int mv_waveglow_create(const mv_waveglow_cfg* cfg, const mv_tensor* weights, int n_weights, int device, int precision,
-                       mv_handle* out) {
+                       const mv_options* options, mv_handle* out) {
     if (!cfg || !weights || !out || n_weights <= 0) {
         set_error("mv_waveglow_create: null argument");
         return MV_EINVAL;
@@ -702,12 +694,15 @@ int mv_waveglow_create(const mv_waveglow_cfg* cfg, const mv_tensor* weights, int
         set_error("mv_waveglow_create: bad config");
         return MV_EINVAL;
     }
+    mv_options opt;
+    int rc = resolve_options(options, &opt);
+    if (rc) return rc;
     DeviceGuard g(device);
     if (!g.ok) {
         set_error("mv_waveglow_create: cannot select HIP device %d", device);
         return MV_EHIP;
     }
-    int rc = init_kernel_attributes();
+    rc = init_kernel_attributes();
     if (rc) return rc;
     WeightMap W;
     if ((rc = W.load(weights, n_weights))) return rc;
@@ -715,6 +710,7 @@ int mv_waveglow_create(const mv_waveglow_cfg* cfg, const mv_tensor* weights, int
     h->kind = 2;
     h->device = device;
     h->precision = precision;
+    h->opt = opt;
     h->cfg = *cfg;
     if ((rc = waveglow_build(h, W))) {
         delete h;

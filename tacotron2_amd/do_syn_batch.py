@@ -99,13 +99,17 @@ def main(argv=None):
         lengths = [m.shape[1] for m in mels]
     else:
         mels, lengths = batch.synthetic_corpus(args.n, args.seed)
-    # one small warm-up call so weight upload / workspace growth stay out of the timing
-    voc(torch.from_numpy(synth.synthetic_mel(max(lengths), 1)).to(dev)[None])
+    if not lengths or max(lengths) <= 0:
+        raise SystemExit("do_syn_batch: no utterances (empty --mels directory or --n 0)")
+    # warm-up at the largest bucket's shape, so weight upload and the growth of the workspace to its final size stay
+    # out of the timing
+    bk = max(batch.make_buckets(lengths, args.max_batch, args.width), key=lambda b: len(b.indices) * b.tmax)
+    voc(torch.full((len(bk.indices), mels[0].shape[0], bk.tmax), synth.MEL_PAD_VALUE, device=dev), lengths=bk.lengths)
     keep = args.out_dir is not None
     if args.device_mels and args.mels:
         raise SystemExit("--device_mels is for the synthetic corpus")
     res, st = batch.synthesize_shard(voc, mels, lengths, rank=rank, world=world, device=dev, fe_wav=args.fe_wav,
-                                     max_batch=args.max_batch, width=args.width, keep_audio=keep,
+                                     hop=voc.hop, max_batch=args.max_batch, width=args.width, keep_audio=keep,
                                      pipeline=not args.no_pipeline, d2h=not args.no_d2h,
                                      device_mels=args.seed if args.device_mels else None)
     if keep:

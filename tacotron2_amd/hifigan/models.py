@@ -89,9 +89,10 @@ class ResBlock(nn.Module):
 
 
 class Generator(nn.Module):
-    def __init__(self, h, precision=None):
+    def __init__(self, h, precision=None, options=None):
         super().__init__()
         self.h = h
+        self.options = dict(options) if options else None  # mv_options fields (include/melvoc.h); None = defaults
         self.num_kernels = len(h["resblock_kernel_sizes"])
         self.num_upsamples = len(h["upsample_rates"])
         c0 = int(h["upsample_initial_channel"])
@@ -149,8 +150,8 @@ class Generator(nn.Module):
             lengths = _native.device_lengths(lengths, B, T, dev)
         pcm = out == "pcm16"
         wav = torch.empty((B, T * self.hop), dtype=torch.int16 if pcm else torch.float32, device=dev)
-        ws = self._get_workspace(dev, h.workspace_bytes(B, T))
         with torch.cuda.device(dev):
+            ws = _native.workspace(self._workspace, dev, h.workspace_bytes(B, T))
             stream = torch.cuda.current_stream(dev).cuda_stream
             _native.check(_native.lib().mv_hifigan_forward(
                 h.ptr, mel.data_ptr(), lengths.data_ptr() if lengths is not None else None, B, T, wav.data_ptr(),
@@ -175,18 +176,10 @@ class Generator(nn.Module):
         key = (dev.index if dev.index is not None else torch.cuda.current_device(), self.precision)
         h = self._handles.get(key)
         if h is None:
-            h = _native.create_hifigan(self.h, self.native_state(), key[0], _native.PRECISIONS[self.precision])
+            h = _native.create_hifigan(self.h, self.native_state(), key[0], _native.PRECISIONS[self.precision],
+                                       self.options)
             self._handles[key] = h
         return h
-
-    def _get_workspace(self, dev, nbytes):
-        ws = self._workspace.get(dev)
-        if ws is None or ws.numel() < nbytes:
-            ws = None
-            self._workspace.pop(dev, None)
-            ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=dev)
-            self._workspace[dev] = ws
-        return ws
 
     def __getstate__(self):
         d = self.__dict__.copy()

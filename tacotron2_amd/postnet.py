@@ -84,12 +84,8 @@ class Postnet(nn.Module):
         if lengths is not None:
             lengths = _native.device_lengths(lengths, B, T, dev)
         y = torch.empty_like(xin)
-        nbytes = h.workspace_bytes(B, T)
-        ws = self._workspace.get(dev)
-        if ws is None or ws.numel() < nbytes:
-            ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=dev)
-            self._workspace[dev] = ws
         with torch.cuda.device(dev):
+            ws = _native.workspace(self._workspace, dev, h.workspace_bytes(B, T))
             stream = torch.cuda.current_stream(dev).cuda_stream
             _native.check(_native.lib().mv_postnet_forward(
                 h.ptr, xin.data_ptr(), lengths.data_ptr() if lengths is not None else None, B, T, y.data_ptr(),

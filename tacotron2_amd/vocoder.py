@@ -50,7 +50,7 @@ class Vocoder:
 
     def __init__(self, kind, model, sigma=DEFAULT_SIGMA, path=None):
         self.kind, self.model, self.sigma, self.path = kind, model, sigma, path
-        self.hop = 256
+        self.hop = int(getattr(model, "hop", 256))  # HiFi-GAN: prod(upsample_rates); WaveGlow: 256 (glow.py:183-185)
 
     def __call__(self, mel, lengths=None, out="float"):
         if mel.dim() == 2:
@@ -65,7 +65,33 @@ class Vocoder:
         return self(mel, lengths=lengths, out="pcm16")
 
 
-def load_vocoder(path, device="cuda", hifigan_config=None, precision=None, sigma=DEFAULT_SIGMA, hps=None):
+def _waveglow_pickle_allowlist(glow):
+    """What a reference WaveGlow checkpoint (`{'model': <pickled glow.WaveGlow>, ...}`, waveglow/train.py:54-62) may
+    resolve while it unpickles: the three glow classes, the torch.nn containers / layers they hold, the weight-norm
+    hook and the plain-Python scaffolding of a module's __dict__.  Anything else is refused by torch's weights_only
+    unpickler, so a doctored checkpoint cannot run code."""
+    import collections
+
+    allowed = [glow.WaveGlow, glow.WN, glow.Invertible1x1Conv, torch.nn.Conv1d, torch.nn.ConvTranspose1d,
+               torch.nn.ModuleList, collections.OrderedDict, set]
+    try:
+        from torch.nn.utils.weight_norm import WeightNorm  # the hook object old-style weight_norm leaves on a module
+
+        allowed.append(WeightNorm)
+    except ImportError:
+        pass
+    try:
+        from torch.nn.utils import parametrize
+        from torch.nn.utils.parametrizations import _WeightNorm
+
+        allowed += [_WeightNorm, parametrize.ParametrizationList]
+    except ImportError:
+        pass
+    return allowed
+
+
+def load_vocoder(path, device="cuda", hifigan_config=None, precision=None, sigma=DEFAULT_SIGMA, hps=None,
+                 unsafe_pickle=False):
     """Load a vocoder checkpoint the way do_syn.py:144-174 does and return a `Vocoder`.
 
     `hps` may be the YAML hyper-parameter dict: its `vocoder` key (a path) is used when `path` is
@@ -84,9 +110,26 @@ def load_vocoder(path, device="cuda", hifigan_config=None, precision=None, sigma
     if kind == "WAVEGLOW":
         from .waveglow import GLOW_PATH, WaveGlow
 
-        if GLOW_PATH not in sys.path:  # do_syn.py:147 appends 'waveglow'; pickles name module `glow`
+        # do_syn.py:147 appends 'waveglow' to sys.path because the pickle names its classes as module `glow`; here the
+        # native glow module stands under that name for the duration of the load only.  The load itself runs under
+        # torch's restricted unpickler with an allow-list (the reference uses weights_only=False, do_syn.py:148);
+        # `unsafe_pickle=True` is the explicit opt-in for checkpoints that carry other objects.
+        import importlib
+
+        had_path = GLOW_PATH in sys.path
+        if not had_path:
             sys.path.insert(0, GLOW_PATH)
-        model = torch.load(path, map_location="cpu", weights_only=False)["model"]
+        try:
+            _glow = importlib.import_module("glow")  # the native module under the name the pickle asks for
+            if unsafe_pickle:
+                ckpt = torch.load(path, map_location="cpu", weights_only=False)
+            else:
+                with torch.serialization.safe_globals(_waveglow_pickle_allowlist(_glow)):
+                    ckpt = torch.load(path, map_location="cpu", weights_only=True)
+        finally:
+            if not had_path and GLOW_PATH in sys.path:
+                sys.path.remove(GLOW_PATH)
+        model = ckpt["model"]
         model = WaveGlow.remove_weightnorm(model)
         if not hasattr(model, "infer") or not hasattr(model, "native_state"):
             raise RuntimeError("checkpoint did not unpickle into the native glow.WaveGlow (is another `glow` module "

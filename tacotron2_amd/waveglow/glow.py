@@ -139,11 +139,11 @@ class WaveGlow(nn.Module):
         h = self._handle(dev)
         pcm = out == "pcm16"
         wav = torch.empty((B, T * 256), dtype=torch.int16 if pcm else torch.float32, device=dev)
-        ws = self._get_workspace(dev, h.workspace_bytes(B, T))
         import ctypes as C
 
         nptr = (C.c_void_p * len(noise))(*[n.data_ptr() for n in noise])
         with torch.cuda.device(dev):
+            ws = _native.workspace(self.__dict__.setdefault("_mv_workspace", {}), dev, h.workspace_bytes(B, T))
             stream = torch.cuda.current_stream(dev).cuda_stream
             _native.check(_native.lib().mv_waveglow_infer(
                 h.ptr, mel.data_ptr(), lengths.data_ptr() if lengths is not None else None, B, T, nptr, len(noise),
@@ -168,6 +168,16 @@ class WaveGlow(nn.Module):
         self.__dict__["_mv_precision"] = p
         self.__dict__.pop("_mv_handles", None)
 
+    @property
+    def options(self):
+        """mv_options fields (include/melvoc.h) the native handle is created with; None = the defaults"""
+        return self.__dict__.get("_mv_options")
+
+    @options.setter
+    def options(self, o):
+        self.__dict__["_mv_options"] = dict(o) if o else None
+        self.__dict__.pop("_mv_handles", None)
+
     def config(self):
         wn0 = self.WN[0]
         return {
@@ -185,18 +195,10 @@ class WaveGlow(nn.Module):
         key = (dev.index if dev.index is not None else torch.cuda.current_device(), self.precision)
         h = handles.get(key)
         if h is None:
-            h = _native.create_waveglow(self.config(), self.native_state(), key[0], _native.PRECISIONS[self.precision])
+            h = _native.create_waveglow(self.config(), self.native_state(), key[0], _native.PRECISIONS[self.precision],
+                                        self.options)
             handles[key] = h
         return h
-
-    def _get_workspace(self, dev, nbytes):
-        cache = self.__dict__.setdefault("_mv_workspace", {})
-        ws = cache.get(dev)
-        if ws is None or ws.numel() < nbytes:
-            cache.pop(dev, None)
-            ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=dev)
-            cache[dev] = ws
-        return ws
 
     def load_state_dict(self, state_dict, strict=True, **kw):
         out = super().load_state_dict(state_dict, strict=strict, **kw)

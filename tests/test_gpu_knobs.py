@@ -1,50 +1,61 @@
-"""The library's tuning knobs select other kernels for the same arithmetic (layer-by-layer instead of fused, float32
-instead of float16 / bfloat16 storage, the unfolded WaveGlow skip path ...).  They are read once per process, so
-each setting runs the bf16 parity check against the golden vectors in a process of its own; the bar is the same as
-for the defaults (SNR >= 40 dB against the fp32 reference, BASELINE.json)."""
-import json
+"""mv_options (include/melvoc.h) select other kernels for the same arithmetic: layer-by-layer instead of fused,
+float32 instead of float16 / bfloat16 storage between kernels, the reference's WaveGlow skip path instead of the
+folded one.  Options are per handle (the library keeps no process-global state and reads no environment), so every
+setting runs in this one process; the bar is the same as for the defaults (bf16: SNR >= 40 dB against the golden
+vectors captured from the reference, BASELINE.json)."""
+import copy
 import os
-import subprocess
-import sys
 
+import numpy as np
 import pytest
 
+torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+from tacotron2_amd import _native, synth  # noqa: E402
+from tacotron2_amd.hifigan import AttrDict, Generator  # noqa: E402
+from tacotron2_amd.waveglow import WaveGlow  # noqa: E402
 
-CHILD = r"""
-import copy, json, os, sys
-import numpy as np, torch
-sys.path.insert(0, sys.argv[1])
-from tacotron2_amd import synth
-from tacotron2_amd.hifigan import Generator, AttrDict
-from tacotron2_amd.waveglow import WaveGlow
 
-def snr(ref, x):
+def _snr(ref, x):
     ref = np.asarray(ref, np.float64)
     return float(10 * np.log10((ref ** 2).sum() / max(((ref - np.asarray(x, np.float64)) ** 2).sum(), 1e-300)))
 
-gd = os.path.join(sys.argv[1], "tests", "golden")
-out = {}
-d = np.load(os.path.join(gd, "hifigan_v1_T64.npz"))
-g = Generator(AttrDict(synth.HIFIGAN_V1), precision="bf16")
-g.load_state_dict({k: torch.from_numpy(v) for k, v in synth.hifigan_state(synth.HIFIGAN_V1, 0).items()})
-g.eval().cuda()
-mel = torch.from_numpy(synth.synthetic_mel(64, int(d["mel_seed"]))).cuda()
-out["hifigan"] = snr(d["wav"], g(mel[None])[0, 0].cpu().numpy())
-# ragged batch: every row equals its own batch-1 result to well below the bf16 error
-lens = [64, 37, 5]
-x = torch.full((3, 80, 64), synth.MEL_PAD_VALUE)
-for b, n in enumerate(lens):
-    x[b, :, :n] = torch.from_numpy(synth.synthetic_mel(n, 40 + b))
-y = g(x.cuda(), lengths=lens)[:, 0].cpu().numpy()
-solo = g(x[1:2, :, :37].contiguous().cuda())[0, 0].cpu().numpy()
-out["ragged"] = float(np.abs(solo - y[1, :37 * 256]).max())
-out["tail_zero"] = bool(not y[1, 37 * 256:].any() and not y[2, 5 * 256:].any())
 
-for c, name in ((512, "waveglow_c512_T16"), (64, "waveglow_c64_T16")):
-    d = np.load(os.path.join(gd, name + ".npz"))
+HIFIGAN_OPTIONS = [
+    None,                       # the defaults
+    {"fuse": 0},                # one convolution per launch
+    {"fuse": 1},                # fused ResBlock kernels, no whole-stage launches
+    {"io16": 0},                # float32 activations between kernels
+    {"fuse": 1, "io16": 0},
+    {"fuse": 0, "io16": 0},
+]
+
+
+@pytest.mark.parametrize("options", HIFIGAN_OPTIONS, ids=lambda o: str(o))
+def test_hifigan_bf16_parity_under_options(options, golden_dir):
+    d = np.load(os.path.join(golden_dir, "hifigan_v1_T64.npz"))
+    g = Generator(AttrDict(synth.HIFIGAN_V1), precision="bf16", options=options)
+    g.load_state_dict({k: torch.from_numpy(v) for k, v in synth.hifigan_state(synth.HIFIGAN_V1, 0).items()})
+    g.eval().cuda()
+    mel = torch.from_numpy(synth.synthetic_mel(64, int(d["mel_seed"]))).cuda()
+    assert _snr(d["wav"], g(mel[None])[0, 0].cpu().numpy()) >= 40.0
+    # ragged batch: every row equals its own batch-1 result to well below the bf16 error
+    lens = [64, 37, 5]
+    x = torch.full((3, 80, 64), synth.MEL_PAD_VALUE)
+    for b, n in enumerate(lens):
+        x[b, :, :n] = torch.from_numpy(synth.synthetic_mel(n, 40 + b))
+    y = g(x.cuda(), lengths=lens)[:, 0].cpu().numpy()
+    solo = g(x[1:2, :, :37].contiguous().cuda())[0, 0].cpu().numpy()
+    assert float(np.abs(solo - y[1, :37 * 256]).max()) <= 5e-3
+    assert not y[1, 37 * 256:].any() and not y[2, 5 * 256:].any()
+
+
+@pytest.mark.parametrize("options", [None, {"wg_fold": 0}, {"io16": 0}, {"wg_fold": 0, "io16": 0}],
+                         ids=lambda o: str(o))
+@pytest.mark.parametrize("name,c", [("waveglow_c512_T16", 512), ("waveglow_c64_T16", 64)])
+def test_waveglow_bf16_parity_under_options(options, name, c, golden_dir):
+    d = np.load(os.path.join(golden_dir, name + ".npz"))
     cfg = copy.deepcopy(synth.WAVEGLOW_512)
     cfg["WN_config"]["n_channels"] = c
     B, T = int(d["B"]), int(d["T"])
@@ -52,33 +63,15 @@ for c, name in ((512, "waveglow_c512_T16"), (64, "waveglow_c64_T16")):
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.waveglow_state(cfg, int(d["weight_seed"])).items()})
     m.cuda().eval()
     m.precision = "bf16"
+    m.options = options
     mel = torch.from_numpy(np.stack([synth.synthetic_mel(T, int(d["mel_seed"]) + b) for b in range(B)])).cuda()
     noise = [torch.from_numpy(n) for n in synth.waveglow_noise(cfg, B, T, int(d["noise_seed"]))]
-    out[name] = snr(d["wav"], m.infer(mel, sigma=float(d["sigma"]), noise=noise).cpu().numpy())
-print("RESULT " + json.dumps(out))
-"""
-
-KNOBS = [
-    {},  # the defaults, through the same child script
-    {"MV_FUSE": "0", "MV_STAGE": "0"},  # HiFi-GAN layer by layer
-    {"MV_STAGE": "0"},  # fused ResBlock kernels only
-    {"MV_IO16": "0"},  # float32 activations between kernels
-    {"MV_STAGE_SPLIT_C64": "0", "MV_WHOLE_MIN_PCT": "60"},  # wider fusion: whole ResBlocks, one C64 stage launch
-    {"MV_RB_ONE": "0", "MV_EPI_LDS": "0", "MV_XCD_SWIZZLE": "2"},
-    {"MV_WG_FOLD": "0"},  # WaveGlow with the reference's skip path
-    {"MV_WG_OPERAND_BF16": "0", "MV_WG_FOLD_BATCH": "0"},  # float32 operand tensors, fold per layer
-    {"MV_WG_IO16": "1", "MV_WG_CFG": "0"},
-]
+    assert _snr(d["wav"], m.infer(mel, sigma=float(d["sigma"]), noise=noise).cpu().numpy()) >= 40.0
 
 
-@pytest.mark.parametrize("knobs", KNOBS, ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()) or "defaults")
-def test_bf16_parity_under_knobs(knobs):
-    env = dict(os.environ)
-    env.update(knobs)
-    p = subprocess.run([sys.executable, "-c", CHILD, ROOT], env=env, capture_output=True, text=True, timeout=300)
-    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
-    line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][-1]
-    r = json.loads(line[len("RESULT "):])
-    assert r["hifigan"] >= 40.0, r
-    assert r["waveglow_c512_T16"] >= 40.0 and r["waveglow_c64_T16"] >= 40.0, r
-    assert r["ragged"] <= 5e-3 and r["tail_zero"], r
+def test_bad_options_are_refused():
+    with pytest.raises(_native.MelvocError):
+        _native.make_options({"no_such_knob": 1})
+    st = synth.hifigan_state(synth.HIFIGAN_V1, 0)
+    with pytest.raises(_native.MelvocError, match="mv_options"):
+        _native.create_hifigan(synth.HIFIGAN_V1, st, 0, _native.PREC_BF16, {"fuse": 7})

@@ -33,6 +33,24 @@ def test_chunks_concatenate_to_the_whole_call(prec, tol):
     assert np.abs(got - whole).max() <= tol
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_chunks_against_the_reference_golden(prec, golden_dir):
+    """Pinned to the reference, not to this library's own whole call: the concatenated chunks of the 80x500 golden
+    mel against the waveform the reference Generator produced for it (tests/golden/hifigan_v1_T500.npz)."""
+    import os
+
+    d = np.load(os.path.join(golden_dir, "hifigan_v1_T500.npz"))
+    g = _gen(prec)
+    mel = torch.from_numpy(synth.synthetic_mel(500, int(d["mel_seed"]))).cuda()
+    got = np.concatenate([w.cpu().numpy() for w in streaming.stream_hifigan(g, mel, chunk_frames=64)])
+    ref = d["wav"].astype(np.float64)
+    assert got.shape == ref.shape
+    if prec == "fp32":
+        assert np.abs(got - ref).max() <= 1e-3
+    else:
+        assert 10 * np.log10((ref ** 2).sum() / ((ref - got) ** 2).sum()) >= 40.0
+
+
 def test_too_small_a_halo_is_visible():
     g = _gen("fp32")
     mel = torch.from_numpy(synth.synthetic_mel(160, 3)).cuda()

@@ -205,3 +205,26 @@ def test_device_lengths_host_side_check():
     for bad in ([3, 8, 1], [3, -1, 1], [3, 1]):
         with pytest.raises(RuntimeError):
             _native.device_lengths(bad, 3, 7, torch.device("cpu"))
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus N` (the driver's own command shape, no torch.distributed.run around it) must start N
+    ranks itself: the launch / rendezvous / reduction path at world 2 over gloo, with the vocoder step skipped."""
+    import json
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3"],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout  # rank 0 alone prints
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["dry_run"] is True
+    assert rec["sum_audio"] == 2.0 and abs(rec["max_time"] - 0.002) < 1e-12  # SUM and MAX over both ranks
+    # under torch.distributed.run (WORLD_SIZE set) the process is a rank, not a launcher
+    env1 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run"], env=env1,
+                       capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0 and json.loads(p.stdout.strip().splitlines()[-1])["n_gpus"] == 1
