@@ -136,6 +136,20 @@ MV_API int mv_hifigan_create(const mv_hifigan_cfg* cfg, const mv_tensor* weights
 MV_API int mv_hifigan_forward(mv_handle h, const float* mel, const int32_t* lengths, int B, int Tmax, void* wav,
                        int out_format, void* workspace, size_t workspace_bytes, void* stream);
 
+/* mv_hifigan_forward for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops such as do_tts.py-style streaming of short chunks, harnesses that forbid hipMalloc).  It has NO counterpart
+ * in the reference.  Same arguments and results as mv_hifigan_forward minus the workspace: the scratch is a
+ * file-scope device array of MV_STATIC_SCRATCH_BYTES inside the library (each GPU the library runs on holds its own
+ * copy until the process ends; its address is resolved once per device in mv_hifigan_create).  The call allocates
+ * nothing (no hipMalloc / hipFree, no allocating library routine) and returns MV_ENOMEM, launching nothing, when
+ * mv_workspace_bytes(h, B, Tmax) exceeds the buffer: B * Tmax <= ~403 frames for config_v1 (~166 KB per frame),
+ * i.e. 4.7 s of audio per call.  All calls on one GPU share that GPU's array and it keeps the last call's
+ * contents (every kernel writes what it later reads, nothing needs to start at zero): calls that overlap on one
+ * GPU -- other streams, other threads, other handles -- race; serialise them. */
+#define MV_STATIC_SCRATCH_BYTES (64ull << 20)
+MV_API int mv_hifigan_forward_static(mv_handle h, const float* mel, const int32_t* lengths, int B, int Tmax,
+                                     void* wav, int out_format, void* stream);
+
 /* Replaces: torch.load(path)['model'] + WaveGlow.remove_weightnorm + .cuda().eval()
  * (do_syn.py:147-150, waveglow/glow.py:179-205,297-313).  W^-1 of every Invertible1x1Conv is
  * computed here once in fp32 (glow.py:89-95 caches it on first use). */

@@ -22,8 +22,9 @@ EXPORTS = (
     "mv_backend", "mv_last_error", "mv_hifigan_create", "mv_hifigan_forward", "mv_waveglow_create",
     "mv_waveglow_infer", "mv_workspace_bytes", "mv_hop", "mv_macs_per_frame", "mv_destroy", "mv_pcm16",
     "mv_test_conv1d", "mv_test_conv_transpose1d", "mv_profile_begin", "mv_profile_end",
-    "mv_postnet_create", "mv_postnet_forward", "mv_default_options",
+    "mv_postnet_create", "mv_postnet_forward", "mv_default_options", "mv_hifigan_forward_static",
 )
+STATIC_SCRATCH_BYTES = 64 << 20  # MV_STATIC_SCRATCH_BYTES
 
 
 class MelvocError(RuntimeError):
@@ -120,6 +121,7 @@ def lib():
     l.mv_default_options.restype = None
     l.mv_hifigan_create.argtypes = [C.POINTER(mv_hifigan_cfg), C.POINTER(mv_tensor), i32, i32, i32, optp, C.POINTER(vp)]
     l.mv_hifigan_forward.argtypes = [vp, vp, vp, i32, i32, vp, i32, vp, C.c_size_t, vp]
+    l.mv_hifigan_forward_static.argtypes = [vp, vp, vp, i32, i32, vp, i32, vp]
     l.mv_waveglow_create.argtypes = [C.POINTER(mv_waveglow_cfg), C.POINTER(mv_tensor), i32, i32, i32, optp, C.POINTER(vp)]
     l.mv_waveglow_infer.argtypes = [vp, vp, vp, i32, i32, C.POINTER(vp), i32, C.c_float, vp, i32, vp, C.c_size_t, vp]
     l.mv_postnet_create.argtypes = [C.POINTER(mv_postnet_cfg), C.POINTER(mv_tensor), i32, i32, i32, optp, C.POINTER(vp)]

@@ -22,6 +22,7 @@
 // with the weights of those layers packed a second time in the pair-interleaved channel order the fused kernels
 // use (RbPair::c1p / c2p).
 #include <cmath>
+#include <mutex>
 
 #include "fused_rb.h"
 
@@ -33,6 +34,39 @@ static constexpr int kFusedMaxLds = 160 * 1024 - 4352;  // the kernels' static L
 #include "handle.h"
 
 namespace mv {
+
+// ---- mv_hifigan_forward_static: the workspace of callers that cannot allocate -----------------
+// A file-scope device array stands in for the caller's workspace argument.  Every GPU the library runs on holds its
+// own copy (at its own address) from the moment the code object is loaded until the process ends.  In host code the
+// array's NAME is only a stand-in for the symbol, never a device address: static_scratch_ptr() asks the runtime for
+// the address once per device (with that device current) and everything else -- kernel arguments, memsets -- uses
+// the pointer it returns.
+static __device__ __align__(256) unsigned char scratch[MV_STATIC_SCRATCH_BYTES];
+
+constexpr int kMaxDevices = 64;
+static void* g_scratch_ptr[kMaxDevices];  // per device; written once under g_scratch_mu
+static std::mutex g_scratch_mu;
+
+// The current device's copy of `scratch`; MV_EHIP (and *out = nullptr) if the runtime cannot resolve it.
+static int static_scratch_ptr(int device, void** out) {
+    *out = nullptr;
+    if (device < 0 || device >= kMaxDevices) {
+        set_error("static scratch: device %d out of range", device);
+        return MV_EINVAL;
+    }
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        void* ptr = nullptr;
+        MV_HIP(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));  // caller made `device` current
+        if (!ptr || ((uintptr_t)ptr & 255) != 0) {
+            set_error("static scratch: bad symbol address %p on device %d", ptr, device);
+            return MV_EHIP;
+        }
+        g_scratch_ptr[device] = ptr;
+    }
+    *out = g_scratch_ptr[device];
+    return MV_OK;
+}
 
 // ---- fused ResBlock launches (bf16 mode) ------------------------------------------------------
 typedef void (*FusedKernel)(const FusedRbParams);
@@ -713,6 +747,8 @@ int mv_hifigan_create(const mv_hifigan_cfg* cfg, const mv_tensor* weights, int n
     rc = init_kernel_attributes();
     if (rc) return rc;
     if ((rc = init_fused_attributes())) return rc;
+    void* sp = nullptr;  // resolve this device's static scratch now, so that mv_hifigan_forward_static never has to
+    if ((rc = static_scratch_ptr(device, &sp))) return rc;
     WeightMap W;
     if ((rc = W.load(weights, n_weights))) return rc;
     HifiganHandle* h = new HifiganHandle();
@@ -754,6 +790,42 @@ int mv_hifigan_forward(mv_handle hh, const float* mel, const int32_t* lengths, i
     }
     return hifigan_forward(static_cast<HifiganHandle*>(hh), mel, lengths, B, Tmax, wav, out_format, workspace,
                            workspace_bytes, (hipStream_t)stream);
+}
+
+int mv_hifigan_forward_static(mv_handle hh, const float* mel, const int32_t* lengths, int B, int Tmax, void* wav,
+                              int out_format, void* stream) {
+    if (!hh || hh->kind != 1) {
+        set_error("mv_hifigan_forward_static: not a HiFi-GAN handle");
+        return MV_EINVAL;
+    }
+    if (!mel || !wav || B < 1 || Tmax < 1) {
+        set_error("mv_hifigan_forward_static: bad argument (B=%d, Tmax=%d)", B, Tmax);
+        return MV_EINVAL;
+    }
+    if (out_format != MV_OUT_F32 && out_format != MV_OUT_PCM16) {
+        set_error("mv_hifigan_forward_static: unknown output format %d", out_format);
+        return MV_EINVAL;
+    }
+    HifiganHandle* h = static_cast<HifiganHandle*>(hh);
+    // sizes first (in 64 bits: B * Tmax may be anything here), before anything is launched
+    const unsigned long long per_frame = h->workspace_bytes(1, 1);
+    if ((unsigned long long)B * (unsigned long long)Tmax > MV_STATIC_SCRATCH_BYTES / per_frame ||
+        h->workspace_bytes(B, Tmax) > MV_STATIC_SCRATCH_BYTES) {
+        set_error("mv_hifigan_forward_static: B * Tmax = %lld frames need %llu bytes of scratch, the static buffer "
+                  "holds %llu (about %llu frames); use mv_hifigan_forward with a workspace of your own",
+                  (long long)B * Tmax, (unsigned long long)B * Tmax * per_frame,
+                  (unsigned long long)MV_STATIC_SCRATCH_BYTES, (unsigned long long)(MV_STATIC_SCRATCH_BYTES / per_frame));
+        return MV_ENOMEM;
+    }
+    DeviceGuard g(hh->device);
+    if (!g.ok) {
+        set_error("mv_hifigan_forward_static: cannot select HIP device %d", hh->device);
+        return MV_EHIP;
+    }
+    void* sp = nullptr;
+    int rc = static_scratch_ptr(hh->device, &sp);  // resolved at create: a table read here
+    if (rc) return rc;
+    return hifigan_forward(h, mel, lengths, B, Tmax, wav, out_format, sp, MV_STATIC_SCRATCH_BYTES, (hipStream_t)stream);
 }
 
 }  // extern "C"
