@@ -4,7 +4,7 @@
 namespace mv {
 const char* last_error_cstr();
 int build_convT_layer(Layer* L, const HostTensor* w, const HostTensor* b, int Cin, int Cout, int K, int u, int cin_pad,
-                      int cout_pad, bool bf16, int force_cfg);
+                      int cout_pad, int prec, int force_cfg);
 int launch_convT(const Layer& L, const void* x, long long x_bs, int cin_stride, int rows_per_frame, float slope,
                  void* y, long long y_bs, int cout_pad, int K, int u, int pad, const int32_t* lengths, int B,
                  int Tmax, hipStream_t stream, Profiler* prof, int in_f16, int out_f16);
@@ -114,7 +114,7 @@ int mv_test_conv1d(const float* x, const int32_t* lengths, int B, int L, int Cin
     hw.data.assign(w, w + (size_t)Cout * Cin * K);
     if (bias) hb.data.assign(bias, bias + Cout);
     Layer Lr;
-    rc = build_conv1d_layer(&Lr, &hw, bias ? &hb : nullptr, Cin, Cout, K, dilation, Cin, Cout, precision == MV_PREC_BF16);
+    rc = build_conv1d_layer(&Lr, &hw, bias ? &hb : nullptr, Cin, Cout, K, dilation, Cin, Cout, precision);
     if (rc) return rc;
     SrcBind sb{x, (long long)L * Cin, Cin, 1, pre_slope};
     LaunchArgs a;
@@ -144,7 +144,7 @@ int mv_test_conv_transpose1d(const float* x, const int32_t* lengths, int B, int 
     hw.data.assign(w, w + (size_t)Cout * Cin * K);
     if (bias) hb.data.assign(bias, bias + Cout);
     Layer Lr;
-    rc = build_convT_layer(&Lr, &hw, bias ? &hb : nullptr, Cin, Cout, K, stride, Cin, Cout, precision == MV_PREC_BF16, -1);
+    rc = build_convT_layer(&Lr, &hw, bias ? &hb : nullptr, Cin, Cout, K, stride, Cin, Cout, precision, -1);
     if (rc) return rc;
     rc = launch_convT(Lr, x, (long long)L * Cin, Cin, 1, pre_slope, y, (long long)L * stride * Cout, Cout, K, stride,
                       padding, lengths, B, L, (hipStream_t)stream, nullptr, 0, 0);

@@ -52,7 +52,8 @@ struct Layer {
     int npass = 0;
     LayerPass pass[kMaxPass];
     int cfg = 0;  // index into kTileCfgs
-    bool bf16 = false;
+    bool bf16 = false;  // bf16 MFMA operands ...
+    bool x3 = false;    // ... each float32 value as a (hi, lo) pair of them (MV_PREC_BF16X3, conv_mfma.h split_bf16x2)
     int epi = EPI_LINEAR;
     size_t lds_bytes = 0;
     double macs_per_n = 0;  // padded MACs per output row (diagnostics)
@@ -86,7 +87,8 @@ struct SrcSpec {
     std::function<float(int, int, int)> w;
 };
 
-int build_layer(Layer* L, const std::vector<SrcSpec>& srcs, int M, const std::vector<float>& bias, bool bf16, int epi,
+// `prec` is MV_PREC_* (0 fp32, 1 bf16, 2 bf16x3) here and in the builders below
+int build_layer(Layer* L, const std::vector<SrcSpec>& srcs, int M, const std::vector<float>& bias, int prec, int epi,
                 int force_cfg = -1);
 void free_layer(Layer* L);
 
@@ -135,7 +137,7 @@ class WeightMap {
 
 // Conv1d [Cout][Cin][K] as a layer, channels zero-padded to cin_pad / cout_pad (hifigan.hip)
 int build_conv1d_layer(Layer* L, const HostTensor* w, const HostTensor* b, int Cin, int Cout, int K, int dil,
-                       int cin_pad, int cout_pad, bool bf16, int force_cfg = -1, bool pair_interleave = false);
+                       int cin_pad, int cout_pad, int prec, int force_cfg = -1, bool pair_interleave = false);
 
 template <typename T>
 int upload(const std::vector<T>& host, T** dev) {

@@ -193,7 +193,25 @@ __device__ __forceinline__ void stage_tile_raw(char* smem, const ConvPass& cp, c
 // Stage rows [row0, row0+rows) x channels [cin_off, cin_off+cb) of one sequence into LDS.
 // Loads are issued U units at a time before any is consumed, so a block that is alone on its CU
 // pays the HBM latency once per batch instead of once per 16-byte unit.
-template <bool BF16, int NTHREADS>
+// Split-operand mode (MV_PREC_BF16X3): a float32 value travels as TWO bfloat16 operands, hi = bf16(x) and
+// lo = bf16(x - hi); a product w*x is formed as w_hi*x_hi + w_hi*x_lo + w_lo*x_hi on the bf16 MFMA with fp32
+// accumulation (the dropped w_lo*x_lo and the residue of the split are <= 2^-16 relative: measured 5e-5 max-abs on
+// the waveform against 1e-3 allowed for fp32 results, at a third of the bf16 MFMA rate instead of a sixteenth).
+// A staged row holds its cb channels twice: [hi: cb bf16][lo: cb bf16].
+__device__ __forceinline__ void split_bf16x2(const f32x4& a, const f32x4& b, u32x4& hi, u32x4& lo) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const __bf16 h0 = (__bf16)v[2 * i], h1 = (__bf16)v[2 * i + 1];
+        const bf16x2 hh = {h0, h1};
+        const bf16x2 ll = {(__bf16)(v[2 * i] - (float)h0), (__bf16)(v[2 * i + 1] - (float)h1)};
+        hi[i] = __builtin_bit_cast(unsigned, hh);
+        lo[i] = __builtin_bit_cast(unsigned, ll);
+    }
+}
+
+template <bool BF16, int NTHREADS, bool X3 = false>
 __device__ __forceinline__ void stage_tile(char* smem, const ConvPass& cp, const void* src_b, int row0, int rows,
                                            int len_rows, int RS) {
     constexpr int UC = BF16 ? 8 : 4;  // channels per 16-byte LDS unit
@@ -246,10 +264,16 @@ __device__ __forceinline__ void stage_tile(char* smem, const ConvPass& cp, const
                     const f32x4 s1 = y1 * slope;
                     y1 = f32x4{fmaxf(y1[0], s1[0]), fmaxf(y1[1], s1[1]), fmaxf(y1[2], s1[2]), fmaxf(y1[3], s1[3])};
                 }
-                v[0] = pack_bf16(y0[0], y0[1]);
-                v[1] = pack_bf16(y0[2], y0[3]);
-                v[2] = pack_bf16(y1[0], y1[1]);
-                v[3] = pack_bf16(y1[2], y1[3]);
+                if constexpr (X3) {
+                    u32x4 lo;
+                    split_bf16x2(y0, y1, v, lo);
+                    *(u32x4*)(smem + dst[k] + cp.cb * 2) = lo;
+                } else {
+                    v[0] = pack_bf16(y0[0], y0[1]);
+                    v[1] = pack_bf16(y0[2], y0[3]);
+                    v[2] = pack_bf16(y1[0], y1[1]);
+                    v[3] = pack_bf16(y1[2], y1[3]);
+                }
             } else {
                 v = __builtin_bit_cast(u32x4, y0);
             }
@@ -386,14 +410,18 @@ struct APre {
 // paced the loop), B fragments come from LDS one group ahead.  The loop body is branch-free
 // (prefetch indices are clamped, not guarded) so the accumulators stay in place.  DEPTH = 2 keeps two steps
 // in flight instead of four (16 VGPRs less; for the register-bound stage kernels with their short K loops).
-template <bool BF16, int TM, int TN, int DEPTH = 4>
+// X3 (split operands, see split_bf16x2): a tap walks 3*nkc K steps over a row's [hi | lo] halves -- the hi chunks
+// against w_hi, the lo chunks against w_hi, then the hi chunks again against w_lo (the host packs the weight
+// fragments in that order) -- so the B pointer steps back over both halves once per tap.
+template <bool BF16, int TM, int TN, int DEPTH = 4, bool X3 = false>
 __device__ __forceinline__ void mma_pass(f32x4 (&acc)[TM][TN], const char* lds_b, int RS, int ktaps, int dil, int nkc,
                                          const u32x4* wlane, long long mtile_stride,
                                          const APre<TM, DEPTH>* pre = nullptr) {
     static_assert(DEPTH == 2 || DEPTH == 4, "two or four K steps of weights in flight");
     constexpr int G = BPipe<TM, TN>::G, NG = BPipe<TM, TN>::NG;
     constexpr int P1 = NG & 1;  // buffer parity of the 2nd / 4th step of an unrolled group
-    const int S = ktaps * nkc;
+    const int nkv = X3 ? 3 * nkc : nkc;  // K steps per tap
+    const int S = ktaps * nkv;
     const int tap_wrap = dil * RS - nkc * 64;
     u32x4 a0[TM + MV_XA], a1[TM + MV_XA], a2[DEPTH == 4 ? TM + MV_XA : 1], a3[DEPTH == 4 ? TM + MV_XA : 1];
     u32x4 q0[G], q1[G];
@@ -425,7 +453,9 @@ __device__ __forceinline__ void mma_pass(f32x4 (&acc)[TM][TN], const char* lds_b
     load_bgroup<TN, G>(q0, bp, RS, 0);
     auto next_bp = [&](const char* cur) {
         const char* n = cur + 64;
-        if (++kc == nkc) {
+        ++kc;
+        if (X3 && kc == 2 * nkc) n -= 2 * nkc * 64;
+        if (kc == nkv) {
             kc = 0;
             n += tap_wrap;
         }
@@ -492,11 +522,12 @@ __device__ __forceinline__ void store_out(const ConvOut& o, int b, long long e, 
 
 // 4-wave tiles with 64 accumulator registers fit 3 waves per SIMD (<= 168 VGPRs; the allocator lands just above
 // that on its own): a third resident block per CU is what the HBM-bound low-channel layers need (bytes in flight).
-template <bool BF16, int TM, int TN, int WM, int WN, int EPI>
+template <bool BF16, int TM, int TN, int WM, int WN, int EPI, bool X3 = false>
 __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(TM * TN <= 16 && WM * WN == 4 ? 3 : 2)))
 void conv_cl_kernel(const ConvParams p) {
+    static_assert(BF16 || !X3, "split operands are bf16 operands");
     constexpr int MT = 16 * TM * WM, NT = 16 * TN * WN, NTHREADS = WM * WN * 64;
-    constexpr int ES = BF16 ? 2 : 4;
+    constexpr int ES = BF16 && !X3 ? 2 : 4;  // bytes of LDS per staged element (X3: a bf16 pair)
     constexpr int CH = BF16 ? 32 : 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -540,15 +571,16 @@ void conv_cl_kernel(const ConvParams p) {
         const long long src_off = (long long)b * cp.batch_stride;
         const void* src_b = cp.src_f16 ? (const void*)((const _Float16*)cp.src + src_off)
                                        : (const void*)((const float*)cp.src + src_off);
-        if (BF16 && cp.src_f16 == 2)
+        if (BF16 && !X3 && cp.src_f16 == 2)
             stage_tile_raw<NTHREADS>(smem, cp, src_b, n0 - cp.pad_left, rows, len * cp.rows_per_frame, RS);
         else
-            stage_tile<BF16, NTHREADS>(smem, cp, src_b, n0 - cp.pad_left, rows, len * cp.rows_per_frame, RS);
+            stage_tile<BF16, NTHREADS, X3>(smem, cp, src_b, n0 - cp.pad_left, rows, len * cp.rows_per_frame, RS);
         __syncthreads();
         const int nkc = cp.cb / CH;
         const char* lds_b = smem + (wn * TN * 16 + lr) * RS + lg * 16;
-        mma_pass<BF16, TM, TN>(acc, lds_b, RS, cp.ktaps, cp.dil, nkc, wlane + (long long)step_base * 64, mtile_stride);
-        step_base += cp.ktaps * nkc;
+        mma_pass<BF16, TM, TN, 4, X3>(acc, lds_b, RS, cp.ktaps, cp.dil, nkc, wlane + (long long)step_base * 64,
+                                      mtile_stride);
+        step_base += cp.ktaps * nkc * (X3 ? 3 : 1);
     }
 
     // ---- epilogue: lane holds 4 consecutive output channels of one time step per (tm, tn)

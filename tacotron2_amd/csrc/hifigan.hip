@@ -267,7 +267,7 @@ static int bias_check(const HostTensor* b, int64_t n, const char* name) {
 // pair_interleave: weight row 32g + 16t + r holds output channel 32g + 8(r>>2) + 4t + (r&3), the order in which the
 // fused kernels' waves (two M tiles each) own 8 consecutive channels per lane; the bias stays in channel order.
 int build_conv1d_layer(Layer* L, const HostTensor* w, const HostTensor* b, int Cin, int Cout, int K, int dil,
-                       int cin_pad, int cout_pad, bool bf16, int force_cfg, bool pair_interleave) {
+                       int cin_pad, int cout_pad, int prec, int force_cfg, bool pair_interleave) {
     const float* wd = w->data.data();
     SrcSpec s;
     s.C = cin_pad;
@@ -281,13 +281,13 @@ int build_conv1d_layer(Layer* L, const HostTensor* w, const HostTensor* b, int C
     };
     std::vector<float> bias(cout_pad, 0.f);
     for (int i = 0; i < Cout; ++i) bias[i] = b ? b->data[i] : 0.f;
-    return build_layer(L, {s}, cout_pad, bias, bf16, EPI_LINEAR, force_cfg);
+    return build_layer(L, {s}, cout_pad, bias, prec, EPI_LINEAR, force_cfg);
 }
 
 // ConvTranspose1d [Cin][Cout][K], stride u, as a J-tap conv with M = u*cout_pad (phase-major).
 //   out[t = q*u + p - pad][co] = sum_j sum_ci x[q - j][ci] * w[ci][co][p + j*u]
 int build_convT_layer(Layer* L, const HostTensor* w, const HostTensor* b, int Cin, int Cout, int K, int u, int cin_pad,
-                      int cout_pad, bool bf16, int force_cfg = -1) {
+                      int cout_pad, int prec, int force_cfg = -1) {
     const float* wd = w->data.data();
     const int J = (K + u - 1) / u;
     SrcSpec s;
@@ -303,7 +303,7 @@ int build_convT_layer(Layer* L, const HostTensor* w, const HostTensor* b, int Ci
     std::vector<float> bias((size_t)u * cout_pad, 0.f);
     for (int p = 0; p < u; ++p)
         for (int i = 0; i < Cout; ++i) bias[(size_t)p * cout_pad + i] = b ? b->data[i] : 0.f;
-    return build_layer(L, {s}, u * cout_pad, bias, bf16, EPI_LINEAR, force_cfg);
+    return build_layer(L, {s}, u * cout_pad, bias, prec, EPI_LINEAR, force_cfg);
 }
 
 // Launch a transposed-conv layer built by build_convT_layer.
@@ -330,7 +330,7 @@ int launch_convT(const Layer& L, const void* x, long long x_bs, int cin_stride, 
 
 static int hifigan_build(HifiganHandle* h, WeightMap& W) {
     const mv_hifigan_cfg& c = h->cfg;
-    const bool bf16 = h->precision == MV_PREC_BF16;
+    const int bf16 = h->precision;  // MV_PREC_* as the layer builders take it
     char name[160];
     int rc;
     h->nstage = c.num_upsamples;
@@ -395,8 +395,8 @@ static int hifigan_build(HifiganHandle* h, WeightMap& W) {
                                                  bf16)))
                         return rc;
                     (which ? pr.c2 : pr.c1).alg_macs_per_n = (double)Cc * Cc * k;
-                    if (bf16 && (rc = build_conv1d_layer(which ? &pr.c2p : &pr.c1p, cw, cb, Cc, Cc, k, which ? 1 : d, Ccp,
-                                                         Ccp, true, -1, true)))
+                    if (bf16 == MV_PREC_BF16 && (rc = build_conv1d_layer(which ? &pr.c2p : &pr.c1p, cw, cb, Cc, Cc, k, which ? 1 : d, Ccp,
+                                                         Ccp, MV_PREC_BF16, -1, true)))
                         return rc;
                     macs += rows * (double)Cc * Cc * k;
                 }
@@ -727,7 +727,7 @@ int mv_hifigan_create(const mv_hifigan_cfg* cfg, const mv_tensor* weights, int n
         return MV_EINVAL;
     }
     *out = nullptr;
-    if (precision != MV_PREC_FP32 && precision != MV_PREC_BF16) {
+    if (precision != MV_PREC_FP32 && precision != MV_PREC_BF16 && precision != MV_PREC_BF16X3) {
         set_error("mv_hifigan_create: unknown precision %d", precision);
         return MV_EINVAL;
     }

@@ -48,16 +48,19 @@ static inline uint16_t f2bf(float x) {
     return (uint16_t)(u >> 16);
 }
 
-int build_layer(Layer* L, const std::vector<SrcSpec>& srcs, int M, const std::vector<float>& bias, bool bf16, int epi,
+int build_layer(Layer* L, const std::vector<SrcSpec>& srcs, int M, const std::vector<float>& bias, int prec, int epi,
                 int force_cfg) {
+    const bool bf16 = prec != MV_PREC_FP32, x3 = prec == MV_PREC_BF16X3;
     const int CH = bf16 ? 32 : 16;
-    const int ES = bf16 ? 2 : 4;
+    const int ES = bf16 && !x3 ? 2 : 4;  // LDS bytes per staged element (x3: a bf16 pair)
+    const int KV = x3 ? 3 : 1;           // K steps per real k-chunk (x3: hi*hi, hi*lo, lo*hi)
     if (M % 32 != 0 || (int)bias.size() != M) {
         set_error("build_layer: M=%d must be a multiple of 32 with a bias of the same size", M);
         return MV_EINVAL;
     }
     L->M = M;
     L->bf16 = bf16;
+    L->x3 = x3;
     L->epi = epi;
     L->cfg = force_cfg >= 0 ? force_cfg : default_cfg(M);
     const TileCfg& tc = kTileCfgs[L->cfg];
@@ -67,7 +70,10 @@ int build_layer(Layer* L, const std::vector<SrcSpec>& srcs, int M, const std::ve
     }
     // 4-wave tiles: two blocks per CU; the 8-wave tile has the CU to itself
     const bool big = tc.WM * tc.WN >= 8;
-    const size_t lds_budget = (size_t)(bf16 && !big ? 72 : 128) * 1024;  // 4-wave tiles: two blocks per CU (2 x 72 KB of 160)
+#ifndef MV_LDS_KB_FP32
+#define MV_LDS_KB_FP32 50
+#endif
+    const size_t lds_budget = (size_t)(bf16 ? (big ? 128 : 72) : (big ? 128 : MV_LDS_KB_FP32)) * 1024;  // 4-wave tiles: two blocks per CU (2 x 72 KB of 160)
     L->npass = 0;
     L->lds_bytes = 0;
     L->steps_total = 0;
@@ -105,13 +111,13 @@ int build_layer(Layer* L, const std::vector<SrcSpec>& srcs, int M, const std::ve
                 p.dil = s.dil;
                 p.tap0 = g;
                 p.pad_left = s.pad_left - g * s.dil;
-                L->steps_total += p.ktaps * (p.cb / CH);
+                L->steps_total += p.ktaps * (p.cb / CH) * KV;
                 L->lds_bytes = std::max(L->lds_bytes, (size_t)rows * (p.cb * ES + kLdsRowPad));
             }
         L->macs_per_n += (double)M * s.C * s.ktaps;
     }
     // room for the coalescing epilogue's float16 [NT][MT] tile (conv_cl_kernel, epi_lds)
-    if (bf16) L->lds_bytes = std::max(L->lds_bytes, (size_t)tc.NT() * (tc.MT() * (epi == EPI_GATE ? 1 : 2) + 16));
+    if (bf16 && !x3) L->lds_bytes = std::max(L->lds_bytes, (size_t)tc.NT() * (tc.MT() * (epi == EPI_GATE ? 1 : 2) + 16));
     if (L->lds_bytes > 160 * 1024) {
         set_error("build_layer: needs %zu bytes of LDS", L->lds_bytes);
         return MV_EINVAL;
@@ -126,16 +132,28 @@ int build_layer(Layer* L, const std::vector<SrcSpec>& srcs, int M, const std::ve
         for (int pi = 0; pi < L->npass; ++pi) {
             const LayerPass& p = L->pass[pi];
             const SrcSpec& s = srcs[p.src];
+            const int nk = p.cb / CH;
             for (int tap = 0; tap < p.ktaps; ++tap)
-                for (int kc = 0; kc < p.cb / CH; ++kc, ++step)
+                for (int kv = 0; kv < nk * KV; ++kv, ++step)
                     for (int lane = 0; lane < 64; ++lane) {
+                        // x3: steps [0, nk) and [nk, 2nk) carry w_hi (against x_hi, then x_lo), [2nk, 3nk) w_lo
+                        const int kc = kv % nk;
+                        const bool want_lo = x3 && kv >= 2 * nk;
                         const int m = mt * 16 + (lane & 15);
                         const int c0 = p.cin_off + kc * CH + (lane >> 4) * per_lane;
                         uint32_t* dst = &packed[(((size_t)mt * L->steps_total + step) * 64 + lane) * 4];
                         if (bf16) {
+                            auto part = [&](float w) -> uint32_t {
+                                const uint16_t h = f2bf(w);
+                                if (!want_lo) return h;
+                                uint32_t u = (uint32_t)h << 16;
+                                float hf;
+                                memcpy(&hf, &u, 4);
+                                return f2bf(w - hf);
+                            };
                             for (int j = 0; j < 4; ++j) {
-                                const uint32_t lo = f2bf(s.w(m, p.tap0 + tap, c0 + 2 * j));
-                                const uint32_t hi = f2bf(s.w(m, p.tap0 + tap, c0 + 2 * j + 1));
+                                const uint32_t lo = part(s.w(m, p.tap0 + tap, c0 + 2 * j));
+                                const uint32_t hi = part(s.w(m, p.tap0 + tap, c0 + 2 * j + 1));
                                 dst[j] = lo | (hi << 16);
                             }
                         } else {
@@ -164,33 +182,37 @@ void free_layer(Layer* L) {
 // ---- kernel table ---------------------------------------------------------------------------
 typedef void (*ConvKernel)(const ConvParams);
 
-template <bool BF16, int EPI>
+template <bool BF16, int EPI, bool X3>
 static ConvKernel kernel_for(int cfg) {
     switch (cfg) {
-        case 0: return conv_cl_kernel<BF16, 4, 4, 4, 1, EPI>;
-        case 1: return conv_cl_kernel<BF16, 4, 8, 4, 1, EPI>;
-        case 2: return conv_cl_kernel<BF16, 4, 4, 2, 2, EPI>;
-        case 3: return conv_cl_kernel<BF16, 4, 4, 1, 4, EPI>;
-        case 4: return conv_cl_kernel<BF16, 2, 4, 1, 4, EPI>;
-        case 5: return conv_cl_kernel<BF16, 2, 8, 1, 4, EPI>;
-        case 6: return conv_cl_kernel<BF16, 4, 8, 1, 4, EPI>;
-        case 7: return conv_cl_kernel<BF16, 4, 8, 2, 2, EPI>;
-        case 8: return conv_cl_kernel<BF16, 4, 8, 4, 2, EPI>;
+        case 0: return conv_cl_kernel<BF16, 4, 4, 4, 1, EPI, X3>;
+        case 1: return conv_cl_kernel<BF16, 4, 8, 4, 1, EPI, X3>;
+        case 2: return conv_cl_kernel<BF16, 4, 4, 2, 2, EPI, X3>;
+        case 3: return conv_cl_kernel<BF16, 4, 4, 1, 4, EPI, X3>;
+        case 4: return conv_cl_kernel<BF16, 2, 4, 1, 4, EPI, X3>;
+        case 5: return conv_cl_kernel<BF16, 2, 8, 1, 4, EPI, X3>;
+        case 6: return conv_cl_kernel<BF16, 4, 8, 1, 4, EPI, X3>;
+        case 7: return conv_cl_kernel<BF16, 4, 8, 2, 2, EPI, X3>;
+        case 8: return conv_cl_kernel<BF16, 4, 8, 4, 2, EPI, X3>;
     }
     return nullptr;
 }
 
-static ConvKernel pick_kernel(bool bf16, int epi, int cfg) {
-    if (bf16) return epi == EPI_GATE ? kernel_for<true, EPI_GATE>(cfg) : kernel_for<true, EPI_LINEAR>(cfg);
-    return epi == EPI_GATE ? kernel_for<false, EPI_GATE>(cfg) : kernel_for<false, EPI_LINEAR>(cfg);
+// prec: MV_PREC_*
+static ConvKernel pick_kernel(int prec, int epi, int cfg) {
+    if (prec == MV_PREC_BF16X3)
+        return epi == EPI_GATE ? kernel_for<true, EPI_GATE, true>(cfg) : kernel_for<true, EPI_LINEAR, true>(cfg);
+    if (prec == MV_PREC_BF16)
+        return epi == EPI_GATE ? kernel_for<true, EPI_GATE, false>(cfg) : kernel_for<true, EPI_LINEAR, false>(cfg);
+    return epi == EPI_GATE ? kernel_for<false, EPI_GATE, false>(cfg) : kernel_for<false, EPI_LINEAR, false>(cfg);
 }
 
 int init_kernel_attributes() {
     // per device: allow the full 160 KiB of dynamic LDS
-    for (int bf = 0; bf < 2; ++bf)
+    for (int prec = 0; prec < 3; ++prec)
         for (int epi = 0; epi < 2; ++epi)
             for (int c = 0; c < kNumTileCfgs; ++c) {
-                ConvKernel k = pick_kernel(bf != 0, epi, c);
+                ConvKernel k = pick_kernel(prec, epi, c);
                 MV_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             }
     return MV_OK;
@@ -232,8 +254,8 @@ std::string layer_kernel_name(const Layer& L) {
     const TileCfg& tc = kTileCfgs[L.cfg];
     char buf[128];
     // the symbol as rocprofv3 prints it
-    snprintf(buf, sizeof buf, "void mv::conv_cl_kernel<%s, %d, %d, %d, %d, %d>(mv::ConvParams)",
-             L.bf16 ? "true" : "false", tc.TM, tc.TN, tc.WM, tc.WN, L.epi);
+    snprintf(buf, sizeof buf, "void mv::conv_cl_kernel<%s, %d, %d, %d, %d, %d, %s>(mv::ConvParams)",
+             L.bf16 ? "true" : "false", tc.TM, tc.TN, tc.WM, tc.WN, L.epi, L.x3 ? "true" : "false");
     return buf;
 }
 
@@ -289,7 +311,7 @@ int launch_layer(const Layer& L, const SrcBind* srcs, int nsrc, const LaunchArgs
     auto unit_ok = [&](const ConvOut& o) {
         return o.row_stride % 8 == 0 && o.off % 8 == 0 && o.valid_per_frame % 8 == 0 && o.batch_stride % 8 == 0;
     };
-    p.epi_lds = L.bf16 && unit_ok(a.out[0]) && (!two || (a.split % mo == 0 && unit_ok(a.out[1]))) &&
+    p.epi_lds = L.bf16 && !L.x3 && unit_ok(a.out[0]) && (!two || (a.split % mo == 0 && unit_ok(a.out[1]))) &&
                 (L.epi == EPI_LINEAR || !two) && a.resid_batch_stride % 8 == 0;
     // bfloat16 storage (dtype code 2) is for tensors that are only ever MFMA operands: a plain copy on the way in,
     // a plain store on the way out
@@ -322,7 +344,7 @@ int launch_layer(const Layer& L, const SrcBind* srcs, int nsrc, const LaunchArgs
         grid = dim3((nx + 7) / 8 * 8 * ny, 1, (unsigned)a.B);
     }
     dim3 block(tc.WM * tc.WN * 64);
-    ConvKernel k = pick_kernel(L.bf16, L.epi, L.cfg);
+    ConvKernel k = pick_kernel(L.x3 ? MV_PREC_BF16X3 : L.bf16 ? MV_PREC_BF16 : MV_PREC_FP32, L.epi, L.cfg);
     if (prof) prof->begin(stream, layer_kernel_name(L), L.alg_macs_per_n * a.n_rows_per_frame);
     hipLaunchKernelGGL(k, grid, block, L.lds_bytes, stream, p);
     if (prof) prof->end(stream);

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void from_channels_last_kernel(const float* __
 
 static int postnet_build(PostnetHandle* h, WeightMap& W) {
     const mv_postnet_cfg& c = h->cfg;
-    const bool bf16 = h->precision == MV_PREC_BF16;
+    const int bf16 = h->precision;  // MV_PREC_* as the layer builders take it
     const int n = c.n_convolutions, K = c.kernel_size, D = c.dim_data, E = c.embedding_dim;
     h->melp = round_up(D, 32);
     h->Cp = round_up(E, 32);
@@ -167,7 +167,7 @@ int mv_postnet_create(const mv_postnet_cfg* cfg, const mv_tensor* weights, int n
         return MV_EINVAL;
     }
     *out = nullptr;
-    if (precision != MV_PREC_FP32 && precision != MV_PREC_BF16) {
+    if (precision != MV_PREC_FP32 && precision != MV_PREC_BF16 && precision != MV_PREC_BF16X3) {
         set_error("mv_postnet_create: unknown precision %d", precision);
         return MV_EINVAL;
     }

@@ -317,6 +317,7 @@ static int expect(const HostTensor* t, std::initializer_list<int64_t> shape, con
 static int waveglow_build(WaveglowHandle* h, WeightMap& W) {
     const mv_waveglow_cfg& c = h->cfg;
     const bool bf16 = h->precision == MV_PREC_BF16;
+    const int prec = h->precision;  // MV_PREC_* as the layer builders take it
     const int C = c.n_channels, nl = c.n_layers, ks = c.kernel_size, ng = c.n_group, nm = c.n_mel_channels;
     h->C = C;
     h->Cp = round_up(C, 32);
@@ -355,7 +356,7 @@ static int waveglow_build(WaveglowHandle* h, WeightMap& W) {
         std::vector<float> bias(M);
         for (int m = 0; m < M; ++m) bias[m] = b->data[(m % per_row) / ng];
         // always exact fp32: 0.08 % of the FLOPs, and it feeds every flow
-        if ((rc = build_layer(&h->up, {s}, M, bias, false, EPI_LINEAR))) return rc;
+        if ((rc = build_layer(&h->up, {s}, M, bias, MV_PREC_FP32, EPI_LINEAR))) return rc;
         h->up.alg_macs_per_n = (double)nm * nm * K;
     }
     h->flows.resize(c.n_flows);
@@ -456,7 +457,7 @@ static int waveglow_build(WaveglowHandle* h, WeightMap& W) {
             // bf16: 256 x 128 tiles (a weight fragment feeds 8 MFMAs instead of 4: the L1 weight stream paces
             // the 256 x 64 tile)
             const int wide = bf16 && (2 * C) % 256 == 0 ? 1 : -1;
-            if ((rc = build_layer(&f.in_layers[i], {sh, sc}, 2 * C, bias, bf16, EPI_GATE, wide))) return rc;
+            if ((rc = build_layer(&f.in_layers[i], {sh, sc}, 2 * C, bias, prec, EPI_GATE, wide))) return rc;
             f.in_layers[i].alg_macs_per_n = (double)2 * C * C * ks + (double)2 * C * h->ncond;
 
             const int rsC = i < nl - 1 ? 2 * C : C;
@@ -475,7 +476,7 @@ static int waveglow_build(WaveglowHandle* h, WeightMap& W) {
             sa.w = [=](int m, int, int ci) -> float { return ci < C ? rwd[(size_t)m * C + ci] : 0.f; };
             const int rwide = bf16 && rsC % 256 == 0 ? 1 : -1;
             if (!fold) {
-                if ((rc = build_layer(&f.res_skip[i], {sa}, rsC, rb->data, bf16, EPI_LINEAR, rwide))) return rc;
+                if ((rc = build_layer(&f.res_skip[i], {sa}, rsC, rb->data, prec, EPI_LINEAR, rwide))) return rc;
                 f.res_skip[i].alg_macs_per_n = (double)rsC * C;
             } else {
                 const int s0 = rsC - C;  // first skip row of res_skip_layers[i]
@@ -492,7 +493,7 @@ static int waveglow_build(WaveglowHandle* h, WeightMap& W) {
                 if (i < nl - 1) {
                     std::vector<float> rbias(rb->data.begin(), rb->data.begin() + C);
                     const int cfg = C % 256 == 0 ? 0 : -1;
-                    if ((rc = build_layer(&f.res_only[i], {sa}, C, rbias, true, EPI_LINEAR, cfg))) return rc;
+                    if ((rc = build_layer(&f.res_only[i], {sa}, C, rbias, MV_PREC_BF16, EPI_LINEAR, cfg))) return rc;
                     f.res_only[i].alg_macs_per_n = (double)C * C;
                 }
             }
@@ -685,7 +686,7 @@ int mv_waveglow_create(const mv_waveglow_cfg* cfg, const mv_tensor* weights, int
         return MV_EINVAL;
     }
     *out = nullptr;
-    if (precision != MV_PREC_FP32 && precision != MV_PREC_BF16) {
+    if (precision != MV_PREC_FP32 && precision != MV_PREC_BF16 && precision != MV_PREC_BF16X3) {
         set_error("mv_waveglow_create: unknown precision %d", precision);
         return MV_EINVAL;
     }
