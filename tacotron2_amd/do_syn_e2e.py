@@ -1,0 +1,206 @@
+"""End-to-end do_syn (BASELINE.json configs[4]): text symbols -> Tacotron2-shaped mel producer (PyTorch-ROCm,
+tacotron2_amd.acoustic) -> native Postnet -> native vocoder, on 1..8 MI355X, nothing leaving the device between the
+three stages.  What do_syn.py:302-394 does one chunk at a time at batch 1 -- `model.inference`, `par_out +
+postnet(par_out)` (model.py:756), `hgan(...)` / `waveglow.infer(...)`, `32768 * y -> int16` -- runs here per
+length-bucket: the decode loop is batched, the Postnet and the vocoder are libmelvoc calls on the
+decoder's own output tensor (the `.cpu()` hop of do_syn.py:380-381 is gone) and the PCM leaves as int16.
+
+    python -m tacotron2_amd.do_syn_e2e --n 256 --vocoder synthetic-hifigan --dtype bf16
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m tacotron2_amd.do_syn_e2e --n 2048
+
+Utterances are sharded over ranks by bucket, longest-processing-time-first on their frame totals; no data-path
+collective; RCCL gathers one statistics record per rank at the end.  Rank 0 prints the reference's own report line
+(do_syn.py:484), `RTF(Tc2)=... RTF(<vocoder>)=...`, on device-synchronised wall time (the reference uses un-synced
+process time), and one JSON line with both stages' seconds.
+
+Weights are synthetic unless `--tc2` / `--vocoder` name checkpoints.  A random-weight Tacotron2 never raises its stop
+gate, so the synthetic corpus imposes each utterance's decode length (`duree_imposee`, model.py:551): about 7.2 frames
+per symbol, 2-10 s for 24-120 symbols.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import acoustic, batch, do_syn_batch, synth
+
+
+def synthetic_texts(n, seed=1234, lo=24, hi=120, n_symbols=96, steps_per_symbol=3.6):
+    """n symbol sequences + the decoder steps imposed on each (2 frames per step, tc2_french.yaml:61)."""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(lo, hi + 1, size=n)
+    texts = [rng.integers(1, n_symbols, size=int(L)).astype(np.int64) for L in lens]
+    steps = [max(1, int(round(int(L) * steps_per_symbol))) for L in lens]
+    return texts, steps
+
+
+def build_producer(dev, ckpt=None, seed=0, dtype=torch.float32):
+    m = acoustic.MelProducer()
+    if ckpt:
+        sd = torch.load(ckpt, map_location="cpu", weights_only=True)
+        sd = sd.get("state_dict", sd)
+        missing = m.load_state_dict({k: v for k, v in sd.items() if k in m.state_dict()}, strict=False)
+        if missing.missing_keys:
+            raise SystemExit(f"{ckpt}: missing tensors of the first decoder's path: {missing.missing_keys[:5]} ...")
+    else:
+        m.load_state_dict(acoustic.synthetic_state(m, seed))
+    return m.eval().to(dev, dtype)
+
+
+def build_postnet(dev, dtype, ckpt=None):
+    from .postnet import Postnet
+
+    p = Postnet(synth.POSTNET_TC2, 0, precision=dtype)
+    if ckpt:
+        sd = torch.load(ckpt, map_location="cpu", weights_only=True)
+        sd = sd.get("state_dict", sd)
+        p.load_state_dict({k[len("postnet.0."):]: v for k, v in sd.items() if k.startswith("postnet.0.")}, strict=False)
+    else:
+        p.load_state_dict({k: torch.from_numpy(v) for k, v in synth.postnet_state(synth.POSTNET_TC2, 0).items()},
+                          strict=False)
+    return p.eval().to(dev)
+
+
+def synthesize_shard(producer, postnet, voc, texts, steps, rank=0, world=1, device=None, max_batch=32, width=64,
+                     seed=1234, keep_audio=False, sink=None):
+    """This rank's share of the corpus.  Returns ({index: int16 waveform} if keep_audio, stats dict)."""
+    dev = torch.device(device)
+    nfs = producer.frames_per_step
+    frames = [s * nfs for s in steps]
+    buckets = batch.make_buckets(frames, max_batch, width)
+    shards, _ = batch.shard_buckets(buckets, world)
+    st = {"utterances": 0, "frames": 0, "t_tc2": 0.0, "t_post": 0.0, "t_voc": 0.0, "calls": 0, "checksum": 0.0}
+    results = {}
+    csum = torch.zeros((), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize(dev)
+    t_all = time.perf_counter()
+    for bi in shards[rank]:
+        bk = buckets[bi]
+        B = len(bk.indices)
+        lin = [len(texts[i]) for i in bk.indices]
+        text = torch.zeros((B, max(lin)), dtype=torch.long)
+        for b, i in enumerate(bk.indices):
+            text[b, : lin[b]] = torch.from_numpy(texts[i])
+        n_steps = [steps[i] for i in bk.indices]
+        spk = torch.tensor([i % 13 for i in bk.indices])
+        t0 = time.perf_counter()
+        mel, fr, _ = producer.infer(text.to(dev), torch.tensor(lin), spk.to(dev), None, seed=seed, n_steps=n_steps)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        mel = postnet(mel.float(), lengths=fr, add_input=True)  # model.py:756, on the decoder's own tensor
+        torch.cuda.synchronize(dev)
+        t2 = time.perf_counter()
+        pcm = voc(mel, lengths=fr, out="pcm16")  # do_syn.py:389-394 fused: int16 on the device
+        csum += pcm.to(torch.float32).abs().sum(dtype=torch.float64)
+        torch.cuda.synchronize(dev)
+        t3 = time.perf_counter()
+        st["t_tc2"] += t1 - t0
+        st["t_post"] += t2 - t1
+        st["t_voc"] += t3 - t2
+        st["calls"] += 1
+        st["utterances"] += B
+        st["frames"] += bk.cost
+        if keep_audio or sink is not None:
+            host = pcm.cpu().numpy()
+            for b, i in enumerate(bk.indices):
+                a = host[b, : frames[i] * voc.hop]
+                if sink is not None:
+                    sink(i, a)
+                else:
+                    results[i] = a.copy()
+    torch.cuda.synchronize(dev)
+    st["wall"] = time.perf_counter() - t_all
+    st["checksum"] = float(csum.item())
+    st["audio_seconds"] = st["frames"] * voc.hop / 22050.0
+    return results, st
+
+
+def gather(st, dev):
+    import torch.distributed as dist
+
+    keys = ["utterances", "frames", "t_tc2", "t_post", "t_voc", "calls", "checksum", "wall", "audio_seconds"]
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return dict(st, per_rank_wall=[st["wall"]])
+    t = torch.tensor([float(st[k]) for k in keys], dtype=torch.float64)
+    if dist.get_backend() == "nccl":
+        t = t.to(dev)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    rows = [o.cpu().tolist() for o in out]
+    tot = {k: sum(r[j] for r in rows) for j, k in enumerate(keys)}
+    for k in ("t_tc2", "t_post", "t_voc", "wall"):  # ranks run side by side: the job's time is its slowest rank's
+        tot[k] = max(r[keys.index(k)] for r in rows)
+    tot["per_rank_wall"] = [r[keys.index("wall")] for r in rows]
+    return tot
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--n", type=int, default=256)
+    ap.add_argument("--vocoder", default="synthetic-hifigan")
+    ap.add_argument("--tc2", default=None, help="Tacotron2 checkpoint (state_dict); default: synthetic weights")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "bf16x3"], help="Postnet / vocoder precision")
+    ap.add_argument("--tc2_dtype", default="fp32", choices=["fp32", "bf16"], help="PyTorch dtype of the mel producer")
+    ap.add_argument("--max_batch", type=int, default=32)
+    ap.add_argument("--width", type=int, default=64)
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--out_dir", default=None)
+    args = ap.parse_args(argv)
+
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("do_syn_e2e needs an MI355X; the native Postnet / vocoders have no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    producer = build_producer(dev, args.tc2, dtype=torch.bfloat16 if args.tc2_dtype == "bf16" else torch.float32)
+    postnet = build_postnet(dev, args.dtype, args.tc2)
+    voc = do_syn_batch.build_vocoder(args.vocoder, dev, args.dtype)
+    texts, steps = synthetic_texts(args.n, args.seed)
+    if not texts:
+        raise SystemExit("do_syn_e2e: no utterances")
+    # warm-up on the largest bucket's shape (weights, workspaces, MIOpen / rocBLAS plans of the PyTorch side)
+    w_texts, w_steps = texts[: args.max_batch], [8] * min(len(texts), args.max_batch)
+    synthesize_shard(producer, postnet, voc, w_texts, w_steps, device=dev, max_batch=args.max_batch)
+    big = max(steps)
+    synthesize_shard(producer, postnet, voc, texts[:1], [big], device=dev, max_batch=1)
+    sink = None
+    if args.out_dir:
+        os.makedirs(args.out_dir, exist_ok=True)
+        from . import vocoder as vmod
+
+        sink = lambda i, a: vmod.write_wav(os.path.join(args.out_dir, "utt%06d.wav" % i), a)  # noqa: E731
+    _, st = synthesize_shard(producer, postnet, voc, texts, steps, rank=rank, world=world, device=dev,
+                             max_batch=args.max_batch, width=args.width, seed=args.seed, sink=sink)
+    tot = gather(st, dev)
+    if rank == 0:
+        dt_S = tot["audio_seconds"]
+        # the reference's own report line (do_syn.py:484); here the Postnet's time is listed with the vocoder side
+        print("RTF(Tc2)={:.4f} RTF({})={:.4f}".format(tot["t_tc2"] / dt_S, voc.kind,
+                                                     (tot["t_voc"] + tot["t_post"]) / dt_S))
+        print(json.dumps({
+            "n_gpus": world, "utterances": int(tot["utterances"]), "audio_seconds": round(dt_S, 3),
+            "wall_seconds": round(tot["wall"], 4), "audio_s_per_s": round(dt_S / tot["wall"], 2),
+            "tc2_seconds": round(tot["t_tc2"], 4), "postnet_seconds": round(tot["t_post"], 4),
+            "vocoder_seconds": round(tot["t_voc"], 4), "vocoder": voc.kind, "dtype": args.dtype,
+            "tc2_dtype": args.tc2_dtype, "calls": int(tot["calls"]), "checksum": tot["checksum"],
+            "timing": "wall, device-synchronised per stage; per-stage seconds are the slowest rank's; mel producer = "
+                      "batched Tacotron2-shaped PyTorch decode with imposed lengths",
+            "per_rank_wall": [round(w, 4) for w in tot["per_rank_wall"]]}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -237,8 +237,48 @@ def postnet_case(name, hps, seed, lengths, mel_seed):
     print(name, {k: v.shape for k, v in out.items() if k.startswith("post")})
 
 
+def tacotron2_case(name, n_text=23, seed=1234, lgs_max=0.3):
+    """model.py:725-761 `Tacotron2.inference` of the REFERENCE on the CPU (tc2_french.yaml shapes, batch 1, the
+    driver's own settings do_syn.py:100,106,188-189), with the weights of the first decoder's path taken from
+    tacotron2_amd.acoustic.synthetic_state -- the fixture pins MelProducer (the build's batched mel producer for
+    BASELINE configs[4]) to the reference: the state_dict contract (names and shapes) and the decoded mel itself."""
+    import yaml
+
+    import model  # the reference's model.py
+    from tacotron2_amd import acoustic
+
+    with open(os.path.join(REF, "tc2_french.yaml")) as f:
+        hps = yaml.safe_load(f)
+    hps.update(n_symbols=acoustic.TC2_FRENCH["n_symbols"], dim_out_symbols=0, save_embeddings=[], stateful=False,
+               code_PAR=0, mask_padding=False, batch_size=1, lgs_max=lgs_max)
+    torch.manual_seed(0)
+    ref = model.Tacotron2(hps)
+    mine = acoustic.MelProducer(dict(acoustic.TC2_FRENCH, lgs_max=lgs_max))
+    st = acoustic.synthetic_state(mine, 0)
+    ref_sd = ref.state_dict()
+    contract = {}
+    for k, v in st.items():
+        assert k in ref_sd and tuple(ref_sd[k].shape) == tuple(v.shape), k  # every tensor of the mel path exists there
+        contract[k] = list(v.shape)
+    missing = ref.load_state_dict(st, strict=False)
+    assert not missing.unexpected_keys
+    ref.eval()
+    rng = np.random.default_rng(seed)
+    text = torch.from_numpy(rng.integers(1, hps["n_symbols"], size=(1, n_text))).long()
+    spk, style = torch.tensor([[3]]), torch.tensor([[5]])
+    out = ref.inference((text, spk, style), seed)
+    mel, gate = out[0][0], out[2][0]
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), text=text.numpy(), spk=np.int64(3), style=np.int64(5),
+                        seed=np.int64(seed), lgs_max=np.float64(lgs_max), mel=mel.numpy(), gate=gate.numpy(),
+                        contract=json.dumps(contract))
+    print(name, tuple(mel.shape), "mel rms %.4f" % float(mel.pow(2).mean().sqrt()))
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    if "--only-tacotron2" in sys.argv:
+        tacotron2_case("tacotron2_tc2_decode")
+        return
     if "--only-postnet" in sys.argv:
         postnet_case("postnet_tc2_ragged", synth.POSTNET_TC2, 0, [40, 52, 64], 4321)
         return
@@ -260,6 +300,7 @@ def main():
     pcm_case("pcm16_v1_T64")
     waveglow_pickle_case("waveglow_tiny_ref")
     postnet_case("postnet_tc2_ragged", synth.POSTNET_TC2, 0, [40, 52, 64], 4321)
+    tacotron2_case("tacotron2_tc2_decode")
 
 
 if __name__ == "__main__":
