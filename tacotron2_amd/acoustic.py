@@ -121,7 +121,7 @@ class _Encoder(nn.Module):
         for conv in self.convolutions:
             x = F.relu(conv(x))
             if lengths is not None:  # a padded batch: keep the padding at zero so the next conv sees the batch-1 edge
-                x = x * self._mask(lengths, x.size(2), x.device).unsqueeze(1)
+                x = x * self._mask(lengths, x.size(2), x.device).unsqueeze(1).to(x.dtype)
         x = x.transpose(1, 2)
         self.lstm.flatten_parameters()
         if lengths is None:
@@ -179,7 +179,7 @@ class MelProducer(nn.Module):
         B, L = text.shape
         x = self.embedding(text).transpose(1, 2)
         if text_lengths is not None:  # the padding symbols must not reach the first conv's receptive field
-            x = x * _Encoder._mask(text_lengths, L, x.device).unsqueeze(1)
+            x = x * _Encoder._mask(text_lengths, L, x.device).unsqueeze(1).to(x.dtype)
         mem = self.encoder(x, text_lengths)
         for table, idx in ((getattr(self, "speaker_embedding", None), spk), (getattr(self, "style_embedding", None), style)):
             if table is None:
@@ -187,11 +187,12 @@ class MelProducer(nn.Module):
             idx = torch.zeros(B, dtype=torch.long, device=text.device) if idx is None else idx.to(text.device).view(B)
             mem = mem + table(idx)[:, None, :]  # model.py:736-747: added to every position ...
         if text_lengths is not None:  # ... of the text itself (model.py:687 "respect du padding")
-            mem = mem * _Encoder._mask(text_lengths, L, mem.device).unsqueeze(2)
+            mem = mem * _Encoder._mask(text_lengths, L, mem.device).unsqueeze(2).to(mem.dtype)
         return mem
 
     @torch.no_grad()
-    def infer(self, text, text_lengths=None, spk=None, style=None, seed=None, n_steps=None, max_steps=None, poll=16):
+    def infer(self, text, text_lengths=None, spk=None, style=None, seed=None, n_steps=None, max_steps=None, poll=16,
+              graph=None):
         """Batched `Tacotron2.inference` for the first decoder (model.py:725-761 -> 532-569).
 
         text          [B,Lin] symbol ids, right-padded; text_lengths [B] (None: all Lin, no masking -- batch-1 semantics)
@@ -199,6 +200,11 @@ class MelProducer(nn.Module):
                       model.py:551,558: random-weight models never raise their gate)
         max_steps     cap for gate-stopped decoding (default int(lgs_max * fe_data), model.py:551)
         poll          the device is read once every `poll` steps to see whether every utterance has finished
+        graph         replay the decode step from a captured HIP graph (default: on a GPU, when more than 8 steps are
+                      known to run).  One step is ~40 small kernels whose launches, not their arithmetic, set the pace;
+                      captured once per call (states in static buffers, the step index on the device), a step costs
+                      one graph launch.  Same arithmetic; the dropout draws come from the graph-safe generator, so
+                      the samples differ from the eager loop's for one seed.
         Returns (mel [B,80,Tmax] zero-padded, frames [B] int32 on the device, gate [B,steps_max]).
         `seed`: torch.manual_seed(seed) before anything is drawn, as model.py:733 does.
         """
@@ -225,6 +231,10 @@ class MelProducer(nn.Module):
         done_at = torch.full((B,), cap, dtype=torch.int32, device=dev)  # steps kept per utterance
         x = memory.new_zeros(B, out_dim)  # the go frame (model.py:545)
         steps = 0
+        if graph is None:
+            graph = memory.is_cuda and n_steps is not None and cap > 8
+        if graph:
+            return self._infer_graph(dec, memory, pmem, mask, n_steps, cap, poll)
         for t in range(cap):
             x = dec.prenet(x)
             ah, ac = dec.attention_rnn(torch.cat((x, ctx), -1), (ah, ac))
@@ -248,8 +258,66 @@ class MelProducer(nn.Module):
         mel = mels[:steps].transpose(0, 1).reshape(B, steps * dec.nfs, dec.dim_data).transpose(1, 2)  # model.py:447-449
         frames = (done_at.clamp(max=steps) * dec.nfs).to(torch.int32)
         keep = torch.arange(steps * dec.nfs, device=dev)[None, :] < frames[:, None]
-        mel = (mel * keep.unsqueeze(1)).contiguous()
+        mel = (mel * keep.unsqueeze(1).to(mel.dtype)).contiguous()
         return mel, frames, gates[:steps].transpose(0, 1)
+
+
+def _decode_step(dec, memory, pmem, mask, S):
+    """One decoder step (model.py:452-492, 553-562) on the state dict S, in place."""
+    x = dec.prenet(S["x"])
+    ah, ac = dec.attention_rnn(torch.cat((x, S["ctx"]), -1), (S["ah"], S["ac"]))
+    ctx, aw = dec.attention_layer(ah, memory, pmem, torch.stack((S["aw"], S["awc"]), 1), mask)
+    S["awc"].add_(aw)
+    dh, dc = dec.decoder_rnn(torch.cat((ah, ctx), -1), (S["dh"], S["dc"]))
+    hc = torch.cat((dh, ctx), 1)
+    xo = dec.linear_projection(hc)
+    g = dec.gate_layer(hc).squeeze(1)
+    for k, v in (("ah", ah), ("ac", ac), ("ctx", ctx), ("aw", aw), ("dh", dh), ("dc", dc), ("x", xo)):
+        S[k].copy_(v)
+    S["mels"].index_copy_(0, S["t"], xo.unsqueeze(0))
+    S["gates"].index_copy_(0, S["t"], g.unsqueeze(0))
+    # first step whose gate fires ends the utterance, that step included (model.py:555-559)
+    fired = (torch.sigmoid(g) > dec.gate_threshold) & (S["done_at"] == S["cap"])
+    S["done_at"].copy_(torch.where(fired, (S["t"] + 1).to(torch.int32).expand_as(S["done_at"]), S["done_at"]))
+    S["t"].add_(1)
+
+
+def _graph_infer(self, dec, memory, pmem, mask, n_steps, cap, poll):
+    dev, B, Lin = memory.device, memory.size(0), memory.size(1)
+    z = lambda *d: memory.new_zeros(*d)  # noqa: E731
+    out_dim = dec.dim_data * dec.nfs
+    S = {"x": z(B, out_dim), "ah": z(B, dec.arnn), "ac": z(B, dec.arnn), "dh": z(B, dec.drnn), "dc": z(B, dec.drnn),
+         "aw": z(B, Lin), "awc": z(B, Lin), "ctx": z(B, dec.emb), "mels": z(cap + 1, B, out_dim), "gates": z(cap + 1, B),
+         "t": torch.zeros(1, dtype=torch.long, device=dev), "cap": torch.full((B,), cap, dtype=torch.int32, device=dev),
+         "done_at": torch.full((B,), cap, dtype=torch.int32, device=dev)}
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):  # warm-up off the capture (library plans, allocator pools), then rewind the state
+        for _ in range(2):
+            _decode_step(dec, memory, pmem, mask, S)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    for k in ("x", "ah", "ac", "dh", "dc", "aw", "awc", "ctx", "t"):
+        S[k].zero_()
+    S["done_at"].fill_(cap)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        _decode_step(dec, memory, pmem, mask, S)
+    # (the capture itself does not execute the step: the state is still the go state)
+    steps = 0
+    for t in range(cap):
+        g.replay()
+        steps = t + 1
+        if n_steps is None and (t + 1) % poll == 0 and bool((S["done_at"] < cap).all()):
+            break
+    done_at = S["done_at"] if n_steps is None else n_steps
+    mel = S["mels"][:steps].transpose(0, 1).reshape(B, steps * dec.nfs, dec.dim_data).transpose(1, 2)  # model.py:447-449
+    frames = (done_at.clamp(max=steps) * dec.nfs).to(torch.int32)
+    keep = torch.arange(steps * dec.nfs, device=dev)[None, :] < frames[:, None]
+    mel = (mel * keep.unsqueeze(1).to(mel.dtype)).contiguous()
+    return mel, frames, S["gates"][:steps].transpose(0, 1)
+
+
+MelProducer._infer_graph = _graph_infer
 
 
 def synthetic_state(module: nn.Module, seed: int = 0):
