@@ -13,7 +13,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libvocoder_oracle.so")
+# ORACLE_SO: another build of the same source (the ASan + UBSan one of tests/test_oracle_asan.py)
+_SO = os.environ.get("ORACLE_SO") or os.path.join(_HERE, "libvocoder_oracle.so")
 _lib = None
 
 
