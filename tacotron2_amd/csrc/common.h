@@ -88,8 +88,10 @@ struct SrcSpec {
 };
 
 // `prec` is MV_PREC_* (0 fp32, 1 bf16, 2 bf16x3) here and in the builders below
+// one_pass: pack every source as a single [tap][k-chunk] pass whatever its LDS footprint (weights for the fused
+// kernels of fused_rb.h, which keep their own tiles; such a layer is never launched through launch_layer)
 int build_layer(Layer* L, const std::vector<SrcSpec>& srcs, int M, const std::vector<float>& bias, int prec, int epi,
-                int force_cfg = -1);
+                int force_cfg = -1, bool one_pass = false);
 void free_layer(Layer* L);
 
 struct SrcBind {

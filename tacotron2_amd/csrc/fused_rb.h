@@ -101,11 +101,11 @@ struct FusedRbParams {
 };
 
 // acc += conv over the window (the caller initialises acc)
-template <int TM, int TN, int DEPTH = 4>
+template <int TM, int TN, int DEPTH = 4, bool X3 = false>
 __device__ __forceinline__ void conv_window(f32x4 (&acc)[TM][TN], const char* lds_b, int RS, int ktaps, int dil,
                                             int nkc, const u32x4* wlane, long long mtile_stride,
                                             const APre<TM, DEPTH>* pre = nullptr) {
-    mma_pass<true, TM, TN, DEPTH>(acc, lds_b, RS, ktaps, dil, nkc, wlane, mtile_stride, pre);
+    mma_pass<true, TM, TN, DEPTH, X3>(acc, lds_b, RS, ktaps, dil, nkc, wlane, mtile_stride, pre);
 }
 
 // Biases of every conv of a launch live in LDS behind the two tiles ([conv][C] floats, filled once per persistent
@@ -164,6 +164,23 @@ __device__ __forceinline__ unsigned long long pack4_f16_sat(const f32x4& v) {
 __device__ __forceinline__ f32x4 unpack4_f16(unsigned long long q) {
     const f16x4 h = __builtin_bit_cast(f16x4, q);
     return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+}
+
+// ---- split operands (MV_PREC_BF16X3, conv_mfma.h split_bf16x2): an operand row holds its C channels twice,
+// [hi: C bf16][lo: C bf16]; the fragment position of a lane is the same in both halves, C*2 bytes apart.
+template <int C>
+__device__ __forceinline__ void store8_x3(char* dst, const f32x4& a, const f32x4& b, bool keep) {
+    u32x4 hi = {0u, 0u, 0u, 0u}, lo = {0u, 0u, 0u, 0u};
+    if (keep) split_bf16x2(a, b, hi, lo);
+    *(u32x4*)dst = hi;
+    *(u32x4*)(dst + C * 2) = lo;
+}
+template <int C>
+__device__ __forceinline__ void store4_x3(char* dst, const f32x4& a, bool keep) {
+    u32x4 hi = {0u, 0u, 0u, 0u}, lo = {0u, 0u, 0u, 0u};
+    if (keep) split_bf16x2(a, a, hi, lo);
+    *(unsigned long long*)dst = ((unsigned long long)hi[1] << 32) | hi[0];
+    *(unsigned long long*)(dst + C * 2) = ((unsigned long long)lo[1] << 32) | lo[0];
 }
 
 // threadIdx.x behind an opaque move: index arithmetic derived from it is recomputed where it is used
@@ -385,13 +402,17 @@ __device__ __forceinline__ void store_window16(_Float16* ob, const char* T0, int
 // reason as in fused_stage_kernel (one variant per function keeps the register allocator from spilling).
 // ONE: a single (conv, conv) pair per launch, known at compile time (most launches: the pair loop and the
 // hand-over to a next pair drop out).
-template <int C, int WM, int WN, int TN, bool IO16X = false, bool ONE = false>
+// X3: split bf16 operands (MV_PREC_BF16X3), float32 window IO; the tiles hold (hi, lo) pairs, every conv runs three
+// K steps per k-chunk (mma_pass), and the first pair's apron rows are loaded as float32.
+template <int C, int WM, int WN, int TN, bool IO16X = false, bool ONE = false, bool X3 = false>
 __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbParams p) {
+    static_assert(!(X3 && IO16X), "split operands keep float32 activations between kernels");
     constexpr int TM = C / 16 / WM;
     constexpr int W = 16 * TN * WN;
     constexpr int NTHREADS = WM * WN * 64;
-    constexpr int RS = C * 2 + kLdsRowPad;
+    constexpr int RS = C * (X3 ? 4 : 2) + kLdsRowPad;
     constexpr int NKC = C / 32;
+    constexpr int KV = X3 ? 3 : 1;  // K steps per k-chunk
     using WL = WinLoad<C, W, NTHREADS>;
     using AL = ApronLoad<C, NTHREADS>;
     static_assert(TM * 16 * WM == C, "C must split evenly over the M waves");
@@ -447,7 +468,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
     const int frag0 = (wn * TN * 16 + lr) * RS + chl * 2;
     constexpr int FRAG_TN = 16 * RS;
 
-    const long long mtile_stride = (long long)p.K * NKC * 64;
+    const long long mtile_stride = (long long)p.K * NKC * 64 * KV;
     const long long woff = (long long)(wm * TM) * mtile_stride + lane;
     const int pad2 = (p.K - 1) / 2;
     constexpr bool io16x = IO16X;             // float16 windows come and go through LDS, next one prefetched
@@ -470,7 +491,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
     // the first weight fragments of every conv are requested while the conv before it winds down (epilogue,
     // barrier, window hand-over), so no K loop starts by waiting an L2 round trip
     APre<TM> wpre;
-    wpre.request((const u32x4*)p.w1[0] + woff, mtile_stride, p.K * NKC);
+    wpre.request((const u32x4*)p.w1[0] + woff, mtile_stride, p.K * NKC * KV);
     f32x4 bias[TM];  // of the conv that runs next, read while the conv before it winds down
     lds_bias(bias, bias_s, 0, C, chl);
     for (;;) {
@@ -503,7 +524,23 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
                     f32x4 q = {0.f, 0.f, 0.f, 0.f};
                     if (in_seq) q = ld4(xb, (long long)g * C + ch, p.io16);
                     X[tm][tn] = q;
-                    *(unsigned long long*)(A0 + n * RS + ch * 2) = pack4_bf16_lrelu(q, 0.1f, in_seq);
+                    if constexpr (X3)
+                        store4_x3<C>(A0 + n * RS + ch * 2, lrelu4(q, 0.1f), in_seq);
+                    else
+                        *(unsigned long long*)(A0 + n * RS + ch * 2) = pack4_bf16_lrelu(q, 0.1f, in_seq);
+                }
+            }
+            if constexpr (X3) {
+                // apron rows of the first pair (see issue_apron16), from the float32 tensor
+                const int total = 2 * p.g1 * (C / 4);
+                for (int idx = tid_here(); idx < total; idx += NTHREADS) {
+                    const int r = idx / (C / 4), u = idx - r * (C / 4);
+                    const int row = r < p.g1 ? r - p.g1 : W + r - p.g1;
+                    const int g = t0 + row;
+                    const bool ok = g >= 0 && g < len;
+                    f32x4 q = {0.f, 0.f, 0.f, 0.f};
+                    if (ok) q = ld4(xb, (long long)g * C + u * 4, 0);
+                    store4_x3<C>(A0 + row * RS + u * 8, lrelu4(q, 0.1f), ok);
                 }
             }
         }
@@ -533,11 +570,11 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = bias[tm];
-            conv_window<TM, TN>(acc, A0 + ((wn * TN * 16 + lr) - pad1) * RS + lg * 16, RS, p.K, d, NKC,
-                                (const u32x4*)p.w1[m] + woff, mtile_stride, &wpre);
+            conv_window<TM, TN, 4, X3>(acc, A0 + ((wn * TN * 16 + lr) - pad1) * RS + lg * 16, RS, p.K, d, NKC,
+                                       (const u32x4*)p.w1[m] + woff, mtile_stride, &wpre);
             MV_LAP(tr, TR_KLOOP);
             lds_bias(bias, bias_s, 2 * m + 1, C, chl);
-            wpre.request((const u32x4*)p.w2[m] + woff, mtile_stride, p.K * NKC);
+            wpre.request((const u32x4*)p.w2[m] + woff, mtile_stride, p.K * NKC * KV);
             // Prefetch: conv1 of the last pair is done with the A tile after the next barrier and nothing reads
             // it again until the next window, so the next window's rows are requested here (their HBM latency
             // hides under this epilogue and the barrier) and dropped into the A tile before conv2 starts.
@@ -548,7 +585,14 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
                 issue_apron16<C, W, NTHREADS>((const _Float16*)p.x + (long long)bn * p.batch_stride, t0n, lenn, p.g1,
                                               rawa);
             }
-            if (interior) {
+            if constexpr (X3) {
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const int g = t0 + (wn * TN + tn) * 16 + lr;
+                    store8_x3<C>(Y0 + frag0 + tn * FRAG_TN, lrelu4(acc[0][tn], 0.1f), lrelu4(acc[1][tn], 0.1f),
+                                 interior || (g >= 0 && g < len));
+                }
+            } else if (interior) {
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
                     *(u32x4*)(Y0 + frag0 + tn * FRAG_TN) = pack8_bf16(lrelu4(acc[0][tn], 0.1f), lrelu4(acc[1][tn], 0.1f));
@@ -574,17 +618,21 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) X[tm][tn] += bias[tm];
-            conv_window<TM, TN>(X, Y0 + ((wn * TN * 16 + lr) - pad2) * RS + lg * 16, RS, p.K, 1, NKC,
-                                (const u32x4*)p.w2[m] + woff, mtile_stride, &wpre);
+            conv_window<TM, TN, 4, X3>(X, Y0 + ((wn * TN * 16 + lr) - pad2) * RS + lg * 16, RS, p.K, 1, NKC,
+                                       (const u32x4*)p.w2[m] + woff, mtile_stride, &wpre);
             MV_LAP(tr, TR_KLOOP);
             lds_bias(bias, bias_s, 2 * m_next, C, chl);
-            wpre.request((const u32x4*)p.w1[m_next] + woff, mtile_stride, p.K * NKC);
+            wpre.request((const u32x4*)p.w1[m_next] + woff, mtile_stride, p.K * NKC * KV);
             if (m + 1 < npair) {
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) {
                     const int g = t0 + (wn * TN + tn) * 16 + lr;
-                    *(u32x4*)(A0 + frag0 + tn * FRAG_TN) =
-                        pack8_bf16_lrelu(X[0][tn], X[1][tn], 0.1f, interior || (g >= 0 && g < len));
+                    if constexpr (X3)
+                        store8_x3<C>(A0 + frag0 + tn * FRAG_TN, lrelu4(X[0][tn], 0.1f), lrelu4(X[1][tn], 0.1f),
+                                     interior || (g >= 0 && g < len));
+                    else
+                        *(u32x4*)(A0 + frag0 + tn * FRAG_TN) =
+                            pack8_bf16_lrelu(X[0][tn], X[1][tn], 0.1f, interior || (g >= 0 && g < len));
                 }
             }
         }

@@ -75,14 +75,16 @@ struct FusedCfg {
     FusedKernel k;        // float32 window IO
     FusedKernel k16;      // float16 window IO through LDS
     FusedKernel k16_one;  // ... specialised for one pair per launch
+    bool x3;              // split bf16 operands (MV_PREC_BF16X3): `k` only, tiles twice as wide per row
     int W() const { return 16 * TN * WN; }
     int threads() const { return 64 * WM * WN; }
+    int RS() const { return C * (x3 ? 4 : 2) + kLdsRowPad; }
 };
 // 8 waves (two per SIMD): the second wave hides LDS / L2 latency and the epilogue phases
 #define MV_FUSED_CFG(C, WM, WN, TN, NPAIR)                                                  \
     {                                                                                       \
         C, WM, WN, TN, NPAIR, fused_rb_kernel<C, WM, WN, TN>, fused_rb_kernel<C, WM, WN, TN, true>, \
-            fused_rb_kernel<C, WM, WN, TN, true, true>                                      \
+            fused_rb_kernel<C, WM, WN, TN, true, true>, false                               \
     }
 static const FusedCfg kFused[] = {
     MV_FUSED_CFG(32, 1, 8, 6, 3),
@@ -90,13 +92,27 @@ static const FusedCfg kFused[] = {
     MV_FUSED_CFG(128, 4, 2, 7, 3),
     MV_FUSED_CFG(256, 8, 1, 7, 1),
 };
+// split operands: the (hi, lo) tiles take twice the LDS per row, so the windows are half as long; C = 256 does not
+// fit a useful window and stays layer by layer
+#define MV_FUSED_X3(C, WM, WN, TN, NPAIR) \
+    { C, WM, WN, TN, NPAIR, fused_rb_kernel<C, WM, WN, TN, false, false, true>, nullptr, nullptr, true }
+static const FusedCfg kFusedX3[] = {
+    MV_FUSED_X3(32, 1, 8, 3, 3),
+    MV_FUSED_X3(64, 2, 4, 3, 3),
+    MV_FUSED_X3(128, 4, 2, 3, 3),
+};
 
 // launch-shape thresholds (measured on the bench batch)
 constexpr int kWholeMinPct = 80;  // a whole ResBlock in one launch while NT / W is at least this
 constexpr int kPairMinPct = 60;   // a lone (conv, conv) pair below this recomputes too much halo: layer by layer
 constexpr int kStageMinPct = 55;  // likewise for a whole-stage launch
 
-static const FusedCfg* fused_cfg_for(int Cp) {
+static const FusedCfg* fused_cfg_for(int Cp, int precision) {
+    if (precision == MV_PREC_BF16X3) {
+        for (const FusedCfg& f : kFusedX3)
+            if (f.C == Cp) return &f;
+        return nullptr;
+    }
     for (const FusedCfg& f : kFused)
         if (f.C == Cp) return &f;
     return nullptr;
@@ -108,7 +124,7 @@ static bool fuse_whole(const FusedCfg& fc, int K, const int* dils, int io16) {
     if (fc.npair < 3) return false;
     int H = 0;
     for (int m = 0; m < 3; ++m) H += (K - 1) / 2 * (dils[m] + 1);
-    if (io16 && fc.k16 && dils[0] * (K - 1) / 2 <= kMaxApron) H -= dils[0] * (K - 1) / 2;  // see launch_fused_rb
+    if (((io16 && fc.k16) || fc.x3) && dils[0] * (K - 1) / 2 <= kMaxApron) H -= dils[0] * (K - 1) / 2;  // see launch_fused_rb
     return (fc.W() - 2 * H) * 100 >= fc.W() * kWholeMinPct;
 }
 
@@ -138,6 +154,8 @@ static const StageCfg* stage_cfg_for(int Cp) {
 }
 
 int init_fused_attributes() {
+    for (const FusedCfg& f : kFusedX3)
+        MV_HIP(hipFuncSetAttribute((const void*)f.k, hipFuncAttributeMaxDynamicSharedMemorySize, kFusedMaxLds));
     for (const FusedCfg& f : kFused) {
         MV_HIP(hipFuncSetAttribute((const void*)f.k, hipFuncAttributeMaxDynamicSharedMemorySize, kFusedMaxLds));
         if (f.k16)
@@ -281,7 +299,7 @@ int build_conv1d_layer(Layer* L, const HostTensor* w, const HostTensor* b, int C
     };
     std::vector<float> bias(cout_pad, 0.f);
     for (int i = 0; i < Cout; ++i) bias[i] = b ? b->data[i] : 0.f;
-    return build_layer(L, {s}, cout_pad, bias, prec, EPI_LINEAR, force_cfg);
+    return build_layer(L, {s}, cout_pad, bias, prec, EPI_LINEAR, force_cfg, pair_interleave);
 }
 
 // ConvTranspose1d [Cin][Cout][K], stride u, as a J-tap conv with M = u*cout_pad (phase-major).
@@ -395,8 +413,8 @@ static int hifigan_build(HifiganHandle* h, WeightMap& W) {
                                                  bf16)))
                         return rc;
                     (which ? pr.c2 : pr.c1).alg_macs_per_n = (double)Cc * Cc * k;
-                    if (bf16 == MV_PREC_BF16 && (rc = build_conv1d_layer(which ? &pr.c2p : &pr.c1p, cw, cb, Cc, Cc, k, which ? 1 : d, Ccp,
-                                                         Ccp, MV_PREC_BF16, -1, true)))
+                    if (bf16 != MV_PREC_FP32 && (rc = build_conv1d_layer(which ? &pr.c2p : &pr.c1p, cw, cb, Cc, Cc, k, which ? 1 : d, Ccp,
+                                                         Ccp, bf16, -1, true)))
                         return rc;
                     macs += rows * (double)Cc * Cc * k;
                 }
@@ -462,7 +480,7 @@ static int launch_fused_rb(const FusedCfg& fc, const RbPair* pairs, int m0, int 
         p.b1[i] = pr.c1.bias;
         p.b2[i] = pr.c2.bias;
         // the float16-IO kernels give the first pair's conv1 real rows either side of the window (apron)
-        if (i == 0 && io16 && fc.k16 && dils[m0] * pad2 <= kMaxApron) {
+        if (i == 0 && ((io16 && fc.k16) || fc.x3) && dils[m0] * pad2 <= kMaxApron) {
             p.g1 = dils[m0] * pad2;
             H += pad2;
         } else {
@@ -475,7 +493,7 @@ static int launch_fused_rb(const FusedCfg& fc, const RbPair* pairs, int m0, int 
     p.NT = fc.W() - 2 * H;
     p.guardA = gA;
     p.guardY = pad2;
-    const int RS = fc.C * 2 + kLdsRowPad;
+    const int RS = fc.RS();
     const size_t lds = (size_t)(2 * fc.W() + 2 * gA + 2 * pad2) * RS + (size_t)2 * npair * fc.C * 4;  // tiles + biases
     if (p.NT < 16 || lds > kFusedMaxLds || p.NT * 100 < fc.W() * kPairMinPct || B > kMaxSeq) return MV_EUNSUPPORTED;
     const long long rows = (long long)Tmax * rpf;
@@ -486,8 +504,8 @@ static int launch_fused_rb(const FusedCfg& fc, const RbPair* pairs, int m0, int 
     FusedKernel kern = one ? fc.k16_one : io16 ? fc.k16 : fc.k;
     if (prof) {
         char nm[128], dt[32];  // the symbol as rocprofv3 prints it + which of its launches
-        snprintf(nm, sizeof nm, "void mv::fused_rb_kernel<%d, %d, %d, %d, %s, %s>(mv::FusedRbParams)", fc.C, fc.WM, fc.WN,
-                 fc.TN, io16 ? "true" : "false", one ? "true" : "false");
+        snprintf(nm, sizeof nm, "void mv::fused_rb_kernel<%d, %d, %d, %d, %s, %s, %s>(mv::FusedRbParams)", fc.C, fc.WM,
+                 fc.WN, fc.TN, io16 ? "true" : "false", one ? "true" : "false", fc.x3 ? "true" : "false");
         snprintf(dt, sizeof dt, "k=%d", K);
         prof->begin(stream, nm, macs * rpf, dt);
     }
@@ -627,7 +645,7 @@ static int hifigan_forward(HifiganHandle* h, const float* mel, const int32_t* le
         if ((rc = launch_convT(h->ups[i], cur_in, bs_in, Cin_p, rpf, 0.1f, A, bs, Cp, K, u, (K - u) / 2, lengths, B,
                                Tmax, stream, prof, io16, io16)))
             return rc;
-        const FusedCfg* fc = h->precision == MV_PREC_BF16 && h->opt.fuse >= 1 ? fused_cfg_for(Cp) : nullptr;
+        const FusedCfg* fc = h->precision != MV_PREC_FP32 && h->opt.fuse >= 1 ? fused_cfg_for(Cp, h->precision) : nullptr;
         const StageCfg* sc = h->precision == MV_PREC_BF16 && h->opt.fuse >= 2 ? stage_cfg_for(Cp) : nullptr;
         int j0 = 0;  // ResBlocks [0, j0) are done by a stage launch
         if (sc) {

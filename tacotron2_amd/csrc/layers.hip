@@ -49,7 +49,7 @@ static inline uint16_t f2bf(float x) {
 }
 
 int build_layer(Layer* L, const std::vector<SrcSpec>& srcs, int M, const std::vector<float>& bias, int prec, int epi,
-                int force_cfg) {
+                int force_cfg, bool one_pass) {
     const bool bf16 = prec != MV_PREC_FP32, x3 = prec == MV_PREC_BF16X3;
     const int CH = bf16 ? 32 : 16;
     const int ES = bf16 && !x3 ? 2 : 4;  // LDS bytes per staged element (x3: a bf16 pair)
@@ -85,7 +85,7 @@ int build_layer(Layer* L, const std::vector<SrcSpec>& srcs, int M, const std::ve
             return MV_EINVAL;
         }
         // taps further apart than half a tile share few rows: stage each tap on its own
-        const bool per_tap = s.ktaps > 1 && 2 * s.dil >= tc.NT();
+        const bool per_tap = !one_pass && s.ktaps > 1 && 2 * s.dil >= tc.NT();
         const int groups = per_tap ? s.ktaps : 1;
         const int gtaps = per_tap ? 1 : s.ktaps;
         const int rows = tc.NT() + (gtaps - 1) * s.dil;
@@ -93,7 +93,7 @@ int build_layer(Layer* L, const std::vector<SrcSpec>& srcs, int M, const std::ve
         int nsplit = 1;
         while (true) {
             const int cb = round_up((s.C + nsplit - 1) / nsplit, CH);
-            if ((size_t)rows * (cb * ES + kLdsRowPad) <= lds_budget || cb == CH) break;
+            if (one_pass || (size_t)rows * (cb * ES + kLdsRowPad) <= lds_budget || cb == CH) break;
             ++nsplit;
         }
         const int cb0 = round_up((s.C + nsplit - 1) / nsplit, CH);
@@ -118,6 +118,7 @@ int build_layer(Layer* L, const std::vector<SrcSpec>& srcs, int M, const std::ve
     }
     // room for the coalescing epilogue's float16 [NT][MT] tile (conv_cl_kernel, epi_lds)
     if (bf16 && !x3) L->lds_bytes = std::max(L->lds_bytes, (size_t)tc.NT() * (tc.MT() * (epi == EPI_GATE ? 1 : 2) + 16));
+    if (one_pass) L->lds_bytes = 0;
     if (L->lds_bytes > 160 * 1024) {
         set_error("build_layer: needs %zu bytes of LDS", L->lds_bytes);
         return MV_EINVAL;
