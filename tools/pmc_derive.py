@@ -16,7 +16,7 @@ def main(path):
     cnt = collections.defaultdict(lambda: collections.defaultdict(float))
     seen = set()
     for r in csv.DictReader(open(path)):
-        k = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void mv::", "")[:48]
+        k = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void mv::", "")[:72]
         cnt[k][r["Counter_Name"]] += float(r["Counter_Value"])
         key = (k, r["Dispatch_Id"])
         if key not in seen:

@@ -9,7 +9,7 @@ import sys
 
 def short(name):
     name = re.sub(r"\(.*", "", name)
-    return name.replace("void mv::", "").replace("mv::", "")[:60]
+    return name.replace("void mv::", "").replace("mv::", "")[:72]
 
 
 def main(paths):

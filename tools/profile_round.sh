@@ -8,7 +8,7 @@ root=$(pwd)
 out=$root/gpurun_out/$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline $BENCH_ARGS"
+BENCH="python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras $BENCH_ARGS"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$out/stats" -o st --output-format csv -- $BENCH > "$out/stats.log" 2>&1
 cp $(find "$out/stats" -name '*kernel_stats.csv' | head -1) "$out/kernel_stats.csv"
 pass() {  # name counters...
@@ -21,5 +21,6 @@ pass write WRITE_SIZE TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI
 cd "$root"
 python3 tools/pmc_summary.py $(find "$out"/pmc_* -name '*counter_collection.csv') > "$out/pmc_summary.csv"
 python3 tools/pmc_derive.py $(find "$out/pmc_sq" -name '*counter_collection.csv') > "$out/mfma_util.csv"
+python3 tools/traffic_json.py "$tag" "${WORKLOAD:-hifigan/bf16/B32}" $(find "$out/pmc_fetch" -name '*counter_collection.csv') $(find "$out/pmc_write" -name '*counter_collection.csv') > "$out/traffic.json"
 head -12 "$out/kernel_stats.csv" | cut -c1-160
 cat "$out/mfma_util.csv"
