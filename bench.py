@@ -28,7 +28,9 @@ The JSON line carries, besides the contract's fields,
   waveglow      BASELINE configs[2]: WaveGlow 12 flows x 8 layers x 512 ch, 80x500 mels, sigma 0.666, noise from
                 torch.manual_seed(1234); records B1 and B8 (bf16 operands) and B1_fp32
   pcie          configs[3] on this one GPU with host buffers on both sides (host mels -> PCM16 on the host)
-(the last four at N = 1 only; --no-extras skips fp32 / waveglow / pcie).
+  e2e           configs[4] on this one GPU: batched Tacotron2-shaped decode (PyTorch-ROCm) -> native Postnet -> native
+                vocoder, Tc2 and vocoder seconds separately
+(the last five at N = 1 only; --no-extras skips fp32 / waveglow / pcie / e2e).
 """
 import argparse
 import json
@@ -300,6 +302,28 @@ def pcie_record(torch, dev):
                         "sink, length-bucketed (<= 32 per call), pad / H2D / vocode / D2H overlapped"}
 
 
+def e2e_record(torch, dev):
+    """BASELINE configs[4] on this one GPU: symbols -> batched Tacotron2-shaped decode (PyTorch-ROCm, imposed lengths)
+    -> native Postnet -> native HiFi-GAN, per-stage seconds like do_syn.py:484 (tacotron2_amd/do_syn_e2e.py)."""
+    from tacotron2_amd import do_syn_batch, do_syn_e2e
+
+    producer = do_syn_e2e.build_producer(dev)
+    postnet = do_syn_e2e.build_postnet(dev, "bf16")
+    voc = do_syn_batch.build_vocoder("synthetic-hifigan", dev, "bf16")
+    texts, steps = do_syn_e2e.synthetic_texts(512, 1234)
+    do_syn_e2e.synthesize_shard(producer, postnet, voc, texts[:64], [8] * 64, device=dev)  # warm-up
+    do_syn_e2e.synthesize_shard(producer, postnet, voc, texts[:2], [max(steps)] * 2, device=dev)
+    _, st = do_syn_e2e.synthesize_shard(producer, postnet, voc, texts, steps, device=dev)
+    a = st["audio_seconds"]
+    return {"value": round(a / st["wall"], 2), "unit": "audio-s/s", "utterances": st["utterances"],
+            "audio_seconds": round(a, 2), "wall_s": round(st["wall"], 3), "tc2_s": round(st["t_tc2"], 3),
+            "postnet_s": round(st["t_post"], 4), "vocoder_s": round(st["t_voc"], 4),
+            "rtf_tc2": round(st["t_tc2"] / a, 6), "rtf_vocoder": round((st["t_voc"] + st["t_post"]) / a, 6),
+            "workload": "512 synthetic utterances of 24-120 symbols (1.7-10 s), tc2_french.yaml-shaped mel producer in "
+                        "PyTorch-ROCm fp32 (batched decode, <= 64 per bucket, step replayed from a HIP graph, lengths "
+                        "imposed) -> native Postnet -> native HiFi-GAN V1 bf16 -> PCM16, all on the device"}
+
+
 def run_rank(args):
     import torch
     import torch.distributed as dist
@@ -393,10 +417,11 @@ def run_rank(args):
                 "B1_fp32": side_record(torch, "waveglow", "fp32", 1, dev, 5, 1, args.rows),
                 "B1_bf16x3": side_record(torch, "waveglow", "bf16x3", 1, dev, 10, 2, args.rows),
             }
-            try:
-                line["pcie"] = pcie_record(torch, dev)
-            except Exception as e:  # secondary: never lose the headline to it
-                line["pcie"] = {"error": repr(e)[:200]}
+            for key, fn in (("pcie", pcie_record), ("e2e", e2e_record)):
+                try:
+                    line[key] = fn(torch, dev)
+                except Exception as e:  # secondary: never lose the headline to it
+                    line[key] = {"error": repr(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(torch)
         print(json.dumps(line), flush=True)
