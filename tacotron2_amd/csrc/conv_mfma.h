@@ -106,6 +106,16 @@ __device__ __forceinline__ void mma16(f32x4& acc, const u32x4& a, const u32x4& b
 
 __device__ __forceinline__ float lrelu(float x, float slope) { return x >= 0.f ? x : x * slope; }
 
+// `32768.0 * y` -> host -> numpy astype('int16') as the reference's driver executes it (do_syn.py:11,389-394, x86
+// host: cvttss2si to int32, then the low 16 bits): truncation toward zero, NO clip, wrap-around on overflow, and 0 for
+// NaN or |32768 y| >= 2^31 (the conversion's "integer indefinite" 0x80000000).  Spelled out because the plain C++ cast
+// is undefined there and the GPU's own conversion saturates instead.
+__device__ __forceinline__ int16_t pcm16_of(float y) {
+    const float v = 32768.0f * y;
+    if (!(v >= -2147483648.f && v < 2147483648.f)) return 0;
+    return (int16_t)(int32_t)v;
+}
+
 // Frames of sequence b.  lengths[] comes from the caller of the C ABI: it is clamped into [0, Tmax] where it is read,
 // so an out-of-range entry cannot walk a kernel out of the [B][Tmax * ..] buffers (NULL = every sequence is Tmax long).
 __device__ __forceinline__ int seq_frames(const int32_t* __restrict__ lengths, int b, int Tmax) {

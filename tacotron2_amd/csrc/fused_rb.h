@@ -1054,7 +1054,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
                     y = tanhf(a);
                 }
                 if (p.wav_pcm16)
-                    ((int16_t*)p.wav)[b * Lmax + t] = (int16_t)(int32_t)(32768.0f * y);
+                    ((int16_t*)p.wav)[b * Lmax + t] = pcm16_of(y);
                 else
                     ((float*)p.wav)[b * Lmax + t] = y;
             }

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const void* __restrict__
         y = tanhf(acc);
     }
     if constexpr (PCM)
-        ((int16_t*)out)[(long long)b * L + t] = (int16_t)(int32_t)(32768.0f * y);
+        ((int16_t*)out)[(long long)b * L + t] = pcm16_of(y);
     else
         ((float*)out)[(long long)b * L + t] = y;
 }

@@ -33,7 +33,7 @@ int launch_to_channels_last(const float* x, int B, int C, int T, float* y, int C
 __global__ __launch_bounds__(256) void pcm16_kernel(const float* __restrict__ wav, size_t n, int16_t* __restrict__ pcm) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * 256;
-    for (; i < n; i += stride) pcm[i] = (int16_t)(int32_t)(32768.0f * wav[i]);
+    for (; i < n; i += stride) pcm[i] = pcm16_of(wav[i]);
 }
 
 int launch_pcm16(const float* wav, size_t n, int16_t* pcm, hipStream_t s) {

@@ -276,8 +276,13 @@ __global__ __launch_bounds__(256) void wg_tail_kernel(const void* __restrict__ s
     for (int j = 0; j < n_early; ++j) ar[off - n_early + j] = sigma * noise[((long long)b * n_early + j) * L + l];
 }
 
-static void invert_small(const float* A, int n, float* out) {
+// Gauss-Jordan with partial pivoting in double.  The reference's W.float().inverse() (glow.py:91) raises on a singular
+// matrix; here a pivot below 1e-12 of the largest entry, or a non-finite result, is MV_EINVAL instead of inf / NaN
+// weights that would silently turn every waveform into NaN.
+static int invert_small(const float* A, int n, float* out) {
     double a[8 * 16];
+    double amax = 0;
+    for (int i = 0; i < n * n; ++i) amax = std::max(amax, (double)std::fabs(A[i]));
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) {
             a[i * 2 * n + j] = A[i * n + j];
@@ -290,6 +295,7 @@ static void invert_small(const float* A, int n, float* out) {
         if (p != c)
             for (int j = 0; j < 2 * n; ++j) std::swap(a[c * 2 * n + j], a[p * 2 * n + j]);
         const double d = a[c * 2 * n + c];
+        if (!(std::fabs(d) > 1e-12 * amax)) return MV_EINVAL;
         for (int j = 0; j < 2 * n; ++j) a[c * 2 * n + j] /= d;
         for (int r = 0; r < n; ++r) {
             if (r == c) continue;
@@ -298,7 +304,11 @@ static void invert_small(const float* A, int n, float* out) {
         }
     }
     for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) out[i * n + j] = (float)a[i * 2 * n + n + j];
+        for (int j = 0; j < n; ++j) {
+            out[i * n + j] = (float)a[i * 2 * n + n + j];
+            if (!std::isfinite(out[i * n + j])) return MV_EINVAL;
+        }
+    return MV_OK;
 }
 
 static int expect(const HostTensor* t, std::initializer_list<int64_t> shape, const char* name) {
@@ -377,7 +387,10 @@ static int waveglow_build(WaveglowHandle* h, WeightMap& W) {
         const HostTensor* wi = W.get(name);
         if ((rc = expect(wi, {n_rem, n_rem}, name))) return rc;
         std::vector<float> inv((size_t)n_rem * n_rem);
-        invert_small(wi->data.data(), n_rem, inv.data());
+        if (invert_small(wi->data.data(), n_rem, inv.data())) {
+            set_error("%s is singular (or not finite): no inverse for the reverse 1x1 convolution", name);
+            return MV_EINVAL;
+        }
         if ((rc = upload(inv, &f.winv))) return rc;
 
         snprintf(name, sizeof name, "WN.%d.start.weight", k);

@@ -159,3 +159,21 @@ def test_library_folds_waveglow_weight_norm_pairs_itself():
                   "mv_waveglow_infer")
     ref = c_oracle.waveglow_infer(st, cfg, synth.synthetic_mel(T, 2), [n[0] for n in noise_np], 0.666)
     assert np.abs(wav[0].cpu().numpy() - ref).max() <= 1e-3
+
+
+def test_pcm16_wraps_like_numpy_and_singular_convinv_is_an_error():
+    y = np.array([0.99999, -1.0, 1.0, 1.5, -1.5, 3.0, 1234.5678, 65535.9, 70000.0, -70000.0, 1e10, -1e10, np.inf, -np.inf,
+                  np.nan, 0.0, -0.00001], np.float32)
+    yd = torch.from_numpy(y).cuda()
+    pd = torch.zeros(y.size, dtype=torch.int16, device="cuda")
+    _native.check(_native.lib().mv_pcm16(yd.data_ptr(), y.size, pd.data_ptr(), None), "mv_pcm16")
+    torch.cuda.synchronize()
+    assert np.array_equal(pd.cpu().numpy(), c_oracle.pcm16(y))  # the oracle is pinned to numpy on the CPU side
+    cfg = copy.deepcopy(synth.WAVEGLOW_512)
+    cfg["WN_config"]["n_channels"] = 64
+    st = dict(synth.waveglow_state(cfg, 0))
+    w = st["convinv.3.conv.weight"].copy()
+    w[1] = w[0]  # two equal rows: singular
+    st["convinv.3.conv.weight"] = w
+    with pytest.raises(_native.MelvocError, match="singular"):
+        _native.create_waveglow(cfg, st, 0, _native.PREC_FP32)

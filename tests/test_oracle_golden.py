@@ -177,3 +177,16 @@ def test_postnet_oracles_match_reference(golden_dir):
         assert np.abs(s - d[f"sum.{i}"]).max() < TOL
         t = torch_ref.postnet_forward(st, synth.POSTNET_TC2, x, add_input=True).numpy()
         assert np.abs(t - d[f"sum.{i}"]).max() < TOL
+
+
+def test_pcm16_matches_numpy_outside_the_int16_range():
+    """do_syn.py:389-394 is numpy's astype('int16') of 32768*y: no clip, wrap-around, and 0 beyond the int32 range or
+    for NaN (the x86 conversion's 'integer indefinite').  WaveGlow's output is unbounded, so the wrap is reachable."""
+    import warnings
+
+    y = np.array([0.99999, -1.0, 1.0, 1.5, -1.5, 3.0, 1234.5678, 65535.9, 70000.0, -70000.0, 1e10, -1e10, np.inf, -np.inf,
+                  np.nan, 0.0, -0.00001], np.float32)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = (np.float32(32768.0) * y).astype("int16")
+    assert np.array_equal(c_oracle.pcm16(y), want)
