@@ -63,6 +63,8 @@ def parse(argv=None):
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the fp32 / waveglow / pcie records")
     ap.add_argument("--rows", action="store_true", help="per-kernel table on stderr")
+    ap.add_argument("--options", default=None,
+                    help='mv_options of the benched model as JSON, e.g. \'{"wg_gemm": 0}\' (A/B of kernel structures)')
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / rendezvous / reduce path only: gloo on the CPU, the step is a no-op (tests)")
     return ap.parse_args(argv)
@@ -159,7 +161,7 @@ def profiled_traffic(symbol, model, dtype, batch):
     return None
 
 
-def build_model(torch, model, dtype, batch, rank, dev):
+def build_model(torch, model, dtype, batch, rank, dev, options=None):
     """-> (module, run(), frames per step, workload string, batch)"""
     from tacotron2_amd import synth
 
@@ -167,7 +169,7 @@ def build_model(torch, model, dtype, batch, rank, dev):
         from tacotron2_amd.hifigan import AttrDict, Generator
 
         B = batch or 32
-        m = Generator(AttrDict(synth.HIFIGAN_V1), precision=dtype)
+        m = Generator(AttrDict(synth.HIFIGAN_V1), precision=dtype, options=options)
         sd = synth.hifigan_state(synth.HIFIGAN_V1, 0)
         m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
         m.eval()
@@ -200,6 +202,7 @@ def build_model(torch, model, dtype, batch, rank, dev):
         del sd
         m.eval().to(dev)
         m.precision = dtype
+        m.options = options
         lengths = np.full(B, 500, np.int32)
         mel = torch.from_numpy(np.stack([synth.synthetic_mel(500, 1234 + rank * 100 + b) for b in range(B)])).to(dev)
         torch.manual_seed(1234)
@@ -356,7 +359,8 @@ def run_rank(args):
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    model, run, frames, workload, B = build_model(torch, args.model, args.dtype, args.batch, rank, dev)
+    model, run, frames, workload, B = build_model(torch, args.model, args.dtype, args.batch, rank, dev,
+                                                  json.loads(args.options) if args.options else None)
     audio_s = frames * 256 / SR
 
     def barrier():

@@ -68,7 +68,7 @@ class mv_postnet_cfg(C.Structure):
 
 
 class mv_options(C.Structure):
-    _fields_ = [("fuse", C.c_int), ("io16", C.c_int), ("wg_fold", C.c_int)]
+    _fields_ = [("fuse", C.c_int), ("io16", C.c_int), ("wg_fold", C.c_int), ("wg_gemm", C.c_int)]
 
 
 def make_options(options):
@@ -78,8 +78,8 @@ def make_options(options):
     o = mv_options()
     lib().mv_default_options(C.byref(o))
     for k, v in options.items():
-        if k not in ("fuse", "io16", "wg_fold"):
-            raise MelvocError(f"unknown option {k!r} (mv_options has fuse, io16, wg_fold)")
+        if k not in ("fuse", "io16", "wg_fold", "wg_gemm"):
+            raise MelvocError(f"unknown option {k!r} (mv_options has fuse, io16, wg_fold, wg_gemm)")
         setattr(o, k, int(v))
     return o
 

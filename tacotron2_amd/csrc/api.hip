@@ -14,9 +14,10 @@ namespace mv {
 int resolve_options(const mv_options* in, mv_options* out) {
     mv_default_options(out);
     if (!in) return MV_OK;
-    if (in->fuse < 0 || in->fuse > 2 || in->io16 < 0 || in->io16 > 1 || in->wg_fold < 0 || in->wg_fold > 1) {
-        set_error("mv_options: fuse must be 0..2, io16 and wg_fold 0 or 1 (got %d, %d, %d)", in->fuse, in->io16,
-                  in->wg_fold);
+    if (in->fuse < 0 || in->fuse > 2 || in->io16 < 0 || in->io16 > 1 || in->wg_fold < 0 || in->wg_fold > 1 ||
+        in->wg_gemm < 0 || in->wg_gemm > 2) {
+        set_error("mv_options: fuse and wg_gemm must be 0..2, io16 and wg_fold 0 or 1 (got %d, %d, %d, %d)", in->fuse,
+                  in->io16, in->wg_fold, in->wg_gemm);
         return MV_EINVAL;
     }
     *out = *in;
@@ -35,6 +36,7 @@ void mv_default_options(mv_options* opt) {
     opt->fuse = 2;
     opt->io16 = 1;
     opt->wg_fold = 1;
+    opt->wg_gemm = 1;
 }
 
 const char* mv_last_error(void) { return last_error_cstr(); }

@@ -92,6 +92,7 @@ struct SrcSpec {
 // kernels of fused_rb.h, which keep their own tiles; such a layer is never launched through launch_layer)
 int build_layer(Layer* L, const std::vector<SrcSpec>& srcs, int M, const std::vector<float>& bias, int prec, int epi,
                 int force_cfg = -1, bool one_pass = false);
+int build_gate_gemm_weights(const std::vector<SrcSpec>& srcs, int M, unsigned short** dev);
 void free_layer(Layer* L);
 
 struct SrcBind {
@@ -120,6 +121,14 @@ struct LaunchArgs {
 int launch_layer(const Layer& L, const SrcBind* srcs, int nsrc, const LaunchArgs& a, hipStream_t stream,
                  Profiler* prof = nullptr);
 int init_kernel_attributes();
+
+// WaveGlow's gated in-layer conv as a 256 x 256 LDS-DMA GEMM (gate_gemm.h / gate_gemm.hip)
+struct GateGemmParams;
+int init_gate_gemm_attributes();
+bool gate_gemm_supported(int C, int Cp, int ncond, int ktaps);
+// (build_gate_gemm_weights below: one layer's weights as the kernel reads them, [M][K] bfloat16 row-major with
+// K = (tap, channel) of srcs[0] followed by the channels of srcs[1])
+int launch_gate_gemm(const GateGemmParams& p, int B, hipStream_t stream);
 
 // ---- weight lookup (state-dict names, weight-norm folding) --------------------------------
 struct HostTensor {

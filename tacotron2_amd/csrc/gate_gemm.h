@@ -1,0 +1,333 @@
+// gate_gemm.h -- WaveGlow's gated in-layer convolution as a 256 x 256 tiled GEMM with LDS-DMA staging (gfx950 only).
+//
+//   acts[n][c] = tanh(t) * sigmoid(s),   (t, s) = rows (c, C + c) of
+//   in_layers[i](H)[.][n] + cond_layer(spect)[2C i + .][n]                       waveglow/glow.py:33-40,164-171
+//
+// GEMM view: D[m][n] = sum_k W[m][k] X[n][k];  M = 2C rows in (tanh, sigmoid) 16-row tile pairs, N = time steps of
+// one sequence, K = ktaps x C channels of the residual stream H (tap j reads row n + (j - (ktaps-1)/2) dil, zero
+// outside [0, len)) followed by the n_mel x n_group channels of the upsampled mel.  Both operands are bfloat16 in
+// memory (the weights [M][K] row-major, H / spect channels-last), so a K tile of either one is rows of 128 contiguous
+// bytes and travels global -> LDS by `global_load_lds_dwordx4` without touching a register.
+//
+// Against `conv_cl_kernel<true,4,8,4,1,EPI_GATE>` (256 x 128 tile, activations staged pass by pass with the block
+// waiting on them, weights streamed L2 -> VGPR by every wave): half the bytes into the CU per FLOP, and the K loop
+// never waits for memory -- tile k+2 is requested right after the barrier that frees its buffer and has a whole K
+// tile of MFMAs (>= 2 k cycles per SIMD) to land.
+//
+// Block: 8 waves as 2 (M) x 4 (N), a wave owns 128 x 64 of the 256 x 256 tile = 8 x 4 accumulator tiles of
+// v_mfma_f32_16x16x32_bf16 (128 registers).
+// LDS image: the 16-byte chunk c of row r sits at chunk position c ^ ((r >> 1) & 7) of the row.  The DMA writes
+// lane-linear (base + 16 lane), so the permutation is applied to each lane's SOURCE address; the fragment reads apply
+// the same XOR.  With it the four 16-lane groups of a ds_read_b128 (MI355X LDS: {0-3,12-15,20-27}, ...) each touch
+// 16 distinct 16-byte slots of the 256-byte bank row: conflict-free.
+//
+// K loop.  A wave's tile splits into quadrants (m half, n half); fragments of one m half (8 x ds_read_b128) and of one
+// n half (4) live in registers.  The operands arrive in HALF-STAGES -- for one K tile of 64, the A rows of every
+// wave's m half s and the B rows of every wave's n half s: 32 KiB -- through a ring of five slots (all 160 KiB of LDS):
+// one is being read, one is next, three are in flight (96 KiB per CU: what it takes to keep an L2-served CU at its
+// ~70 GB/s; with two whole-tile buffers and one request per K tile the same loop measured 15 us of 70 waiting on DMA).
+//     P0: read B1  (t, 1)     | MFMA (A0, B0)
+//     P1: read A1  (t, 1)     | MFMA (A0, B1)
+//         hand-over: reads done, own DMA of (t+1, 0) landed [vmcnt(12)], s_barrier; request (t+3, 0) into (t, 1)'s slot
+//     P2: read A0' (t+1, 0)   | MFMA (A1, B0)
+//     P3: read B0' (t+1, 0)   | MFMA (A1, B1)
+//         hand-over: reads done, own DMA of (t+1, 1) landed, s_barrier; request (t+3, 1) into (t+1, 0)'s slot
+// so every fragment read is issued one 16-MFMA phase before its first use and never more than 12 are outstanding.
+#pragma once
+#include "conv_mfma.h"
+
+namespace mv {
+
+struct GateGemmParams {
+    const unsigned short* w;     // [M][K] bfloat16
+    const float* bias;           // [M] (in_layer bias + cond_layer bias), same row order
+    const unsigned short* h;     // [B][L][h_stride] bfloat16: operand copy of the residual stream (Cp channels used)
+    const unsigned short* cond;  // [B][L][ncond] bfloat16: upsampled mel, regrouped
+    unsigned short* out;         // [B][L][Cp] bfloat16: gated activations
+    const unsigned short* zero;  // >= 64 zero bfloat16 values, 16-byte aligned (rows outside a sequence)
+    const int32_t* lengths;      // frames per sequence (NULL: Tmax)
+    int Tmax, spf;               // time steps per frame
+    long long L;                 // rows per sequence in h / cond / out (= Tmax * spf)
+    int Cp, ncond, ktaps, dil;
+    int h_stride;                // elements per row of h (>= Cp)
+    int K;                       // ktaps * Cp + ncond
+    int nx, ny;                  // N tiles per sequence, M blocks (= 2C / 256)
+};
+
+constexpr int kGgTile = 256, kGgBK = 64;
+constexpr int kGgHalfBytes = 128 * kGgBK * 2;         // 128 rows of one operand, one K tile: 16 KiB
+constexpr int kGgSlotBytes = 2 * kGgHalfBytes;        // a half-stage: A part + B part
+constexpr int kGgSlots = 5;
+constexpr int kGgLds = kGgSlots * kGgSlotBytes;       // 160 KiB: the whole LDS of a CU
+constexpr int kGgOutRS = 128 * 2 + 16;                // epilogue tile: 256 rows x 128 channels bf16, padded
+
+// s_waitcnt immediate (gfx9 layout): vmcnt in bits [3:0] and [15:14], lgkmcnt in [11:8], expcnt [6:4] left at "no wait"
+template <int VM, int LGKM>
+constexpr int kGgWait = (VM & 15) | ((VM >> 4) << 14) | 0x70 | (LGKM << 8);
+
+#ifdef MV_GATE_GEMM_KERNEL  // the kernel itself is compiled in gate_gemm.hip only; other units see the parameters
+__device__ __forceinline__ void glds16(const void* src, char* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+#ifdef MV_GG_STAMP  // diagnostic build (tools/gg_stamps.py): shader-clock stamps of block phases, in a buffer of their own
+__device__ unsigned long long gg_stamps[4096][6];
+#define MV_GG_STAMP_AT(i) \
+    if (threadIdx.x == 0) gg_stamps[(blockIdx.y * gridDim.x + blockIdx.x) & 4095][i] = __builtin_amdgcn_s_memtime()
+#else
+#define MV_GG_STAMP_AT(i)
+#endif
+
+__global__ __launch_bounds__(512) void gate_gemm_kernel(const GateGemmParams p) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    MV_GG_STAMP_AT(0);
+    // XCD-aware order (as conv_cl_kernel): the ny M blocks of a row tile run back to back on one XCD
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int by = slot % p.ny;
+    const int bx = (slot / p.ny) * 8 + xcd;
+    if (bx >= p.nx) return;
+    const int b = blockIdx.y;
+    const int len = seq_frames(p.lengths, b, p.Tmax) * p.spf;
+    const int n0 = bx * kGgTile;
+    if (n0 >= len) return;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int lr = lane & 15, lg = lane >> 4;
+
+    // ---- staging.  The unit of the pipeline is a HALF-STAGE = (K tile, half s): the 64 rows of A that each wave row
+    // wr multiplies in its m half s (tile rows 128 wr + 64 s + 0..63) and the 32 rows of B of every wave column's n half
+    // s (tile rows 64 wc + 32 s + 0..31): 128 + 128 rows x 128 B = 32 KiB, five of them in a ring.  Wave w moves pieces
+    // 2w, 2w+1 (8 rows x 128 B each) of the A part and of the B part.  Lane l of a piece fills chunk position l & 7 of
+    // local row 16 w + 8 j + (l >> 3), i.e. it fetches source chunk (l & 7) ^ ((row >> 1) & 7) = (l & 7) ^ (4 j + (l >> 4)).
+    const int srow = lane >> 3;
+    const unsigned c16[2] = {(unsigned)(((lane & 7) ^ (lane >> 4)) * 16), (unsigned)(((lane & 7) ^ (4 + (lane >> 4))) * 16)};
+    const int a_r = (wave >> 2) * 128 + (wave & 3) * 16 + srow;  // tile row of the lane's A piece j, half s: a_r + 8 j + 64 s
+    const int b_r = (wave >> 1) * 64 + (wave & 1) * 16 + srow;   // ... of its B piece: b_r + 8 j + 32 s
+    const unsigned a_row = (unsigned)(by * kGgTile + a_r) * (unsigned)p.K * 2u;
+    const unsigned a_voff[2] = {a_row + c16[0], a_row + 16u * (unsigned)p.K + c16[1]};
+    const int t0 = n0 + b_r;
+    const char* wbase = (const char*)p.w;
+    const char* hb = (const char*)(p.h + (long long)b * p.L * p.h_stride);
+    const char* cb = (const char*)(p.cond + (long long)b * p.L * p.ncond);
+    const char* zb = (const char*)p.zero;
+    const int nkc_h = p.Cp / kGgBK, nkc_c = p.ncond / kGgBK;
+    const int NK = p.ktaps * nkc_h + nkc_c;
+    const int pad = (p.ktaps - 1) / 2 * p.dil;
+
+    const unsigned rs_h = (unsigned)p.h_stride * 2u, rs_c = (unsigned)p.ncond * 2u, a_half = 128u * (unsigned)p.K;
+    const int ktaps = p.ktaps, dil = p.dil;
+    // wave-uniform cursor of the next half-stage to request: segment (tap of H, or ktaps = the cond tensor), K chunk in
+    // it, K tile, half.  A half-stage is requested in two steps of two pieces: its A rows, then its B rows.
+    int seg = 0, kc = 0, sk = 0, sh = 0;
+    auto request_a = [&](int slot_off, int j) {  // piece j of the A rows
+#if !(defined(MV_GG_ABL) && (MV_GG_ABL & 8))  // timing-only: bit 3 = no A requests, bit 4 = no B requests
+        char* la = smem + slot_off + wave * 2048;
+        const char* wk = wbase + (unsigned)sk * 128u + (sh ? a_half : 0u);
+        glds16(wk + a_voff[j], la + j * 1024);
+#endif
+    };
+    auto request_b = [&](int slot_off, int j) {  // piece j of the B rows; j = 1 also steps the cursor
+        char* lb = smem + slot_off + kGgHalfBytes + wave * 2048;
+        const bool is_h = seg < ktaps;
+        const int shift = (is_h ? seg * dil - pad : 0) + 32 * sh;
+        const unsigned rs = is_h ? rs_h : rs_c;
+        const unsigned long long base = (unsigned long long)(is_h ? hb : cb) + (unsigned)kc * 128u;
+        const int tt = t0 + 8 * j + shift;
+        // (a cond row is read for tt = its own time step; outside [0, len) it multiplies nothing that is kept)
+        const bool valid = (unsigned)tt < (unsigned)len;
+        const unsigned voff = (valid ? (unsigned)tt * rs : 0u) + c16[j];
+        const unsigned long long bs = valid ? base : (unsigned long long)zb;
+#if !(defined(MV_GG_ABL) && (MV_GG_ABL & 16))
+        glds16((const char*)(bs + voff), lb + j * 1024);
+#endif
+        if (j == 1) {
+            const bool tile_done = sh == 1;
+            const bool wrap = tile_done && kc + 1 == (is_h ? nkc_h : nkc_c);
+            sh = __builtin_amdgcn_readfirstlane(sh ^ 1);
+            sk = __builtin_amdgcn_readfirstlane(tile_done ? sk + 1 : sk);
+            kc = __builtin_amdgcn_readfirstlane(wrap ? 0 : (tile_done ? kc + 1 : kc));
+            seg = __builtin_amdgcn_readfirstlane(wrap ? seg + 1 : seg);
+        }
+    };
+    auto next_slot = [](int off) { return off + kGgSlotBytes == kGgLds ? 0 : off + kGgSlotBytes; };
+    auto prev_slot = [](int off) { return off == 0 ? kGgLds - kGgSlotBytes : off - kGgSlotBytes; };
+
+    // ---- fragment addresses within a half-stage slot
+    const int swz0 = (lg ^ (lr >> 1)) * 16;  // chunk lg (k = 0..31) of a row; chunk 4 + lg (k = 32..63) is swz0 ^ 64
+    const char* fa = smem + (wr * 64 + lr) * 128;
+    const char* fb = smem + kGgHalfBytes + (wc * 32 + lr) * 128;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x4 A0[4][2], A1[4][2], B0[2][2], B1[2][2];
+
+#if defined(MV_GG_ABL) && (MV_GG_ABL & 2)  // timing-only: bit 1 = no fragment reads in the K loop
+#define MV_GG_RD(dst, src) asm volatile("" : "+v"(dst) : "v"(src))
+#else
+#define MV_GG_RD(dst, src) dst = *(const u32x4*)(src)
+#endif
+    auto read_a = [&](u32x4 (&A)[4][2], int slot_off) {
+        const char* base = fa + slot_off;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            MV_GG_RD(A[i][0], base + i * 2048 + swz0);
+            MV_GG_RD(A[i][1], base + i * 2048 + (swz0 ^ 64));
+        }
+    };
+    auto read_b = [&](u32x4 (&Bf)[2][2], int slot_off) {
+        const char* base = fb + slot_off;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            MV_GG_RD(Bf[i][0], base + i * 2048 + swz0);
+            MV_GG_RD(Bf[i][1], base + i * 2048 + (swz0 ^ 64));
+        }
+    };
+    // the barrier that ends a load part: fragment reads issued, then everybody; the reads are waited for behind it
+    auto bar_then_wait_reads = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+#if !(defined(MV_GG_ABL) && (MV_GG_ABL & 4))  // timing-only: bit 2 = no barriers in the K loop
+        __builtin_amdgcn_s_barrier();
+#endif
+        __builtin_amdgcn_s_waitcnt(kGgWait<63, 0>);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // One multiply part: 16 MFMAs and the barrier that ends it.  (The DMA requests stay in the load parts: issued between
+    // these MFMAs, with the SIMD's other wave in its load part, each request stalled the pipe ~185 cycles: 86 us against 68.)
+    auto quad = [&](const u32x4 (&A)[4][2], const u32x4 (&Bf)[2][2], int mh, int nh) {
+        __builtin_amdgcn_s_setprio(kMfmaPrio);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) mma16<true>(acc[mh * 4 + i][nh * 2 + j], A[i][ks], Bf[j][ks]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+#if !(defined(MV_GG_ABL) && (MV_GG_ABL & 4))
+        __builtin_amdgcn_s_barrier();
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto request = [&](int req, int slot_off) {  // req 1: the A pieces of the half-stage under the cursor, 2: its B pieces
+#if !(defined(MV_GG_ABL) && (MV_GG_ABL & 1))  // timing-only: bit 0 = no DMA in the K loop
+        if (req == 1) {
+            request_a(slot_off, 0);
+            request_a(slot_off, 1);
+        } else if (req == 2) {
+            request_b(slot_off, 0);
+            request_b(slot_off, 1);
+        }
+#endif
+    };
+    // This wave's pieces of the half-stage that a LATER load part reads have landed: in steady state that half-stage is
+    // followed by two younger ones in the wave's request queue (8 pieces); once the cursor has run off the end of K,
+    // fewer are, and the wave waits for everything.  The wait sits one load part before the first read, so that between
+    // the two lies a barrier both wave groups have passed (they run one barrier apart).
+    auto wait_dma = [&]() {
+#if defined(MV_GG_ABL) && (MV_GG_ABL & 128)  // timing-only: bit 7 = requests are never waited for
+        return;
+#endif
+        if (sk < NK)
+            __builtin_amdgcn_s_waitcnt(kGgWait<8, 15>);
+        else
+            __builtin_amdgcn_s_waitcnt(kGgWait<0, 15>);
+    };
+
+    // prologue: fill the ring (H >= 6: the host checks K >= 3 K tiles), half-stage 0 landed
+#pragma unroll
+    for (int i = 0; i < kGgSlots; ++i) {
+        request_a(i * kGgSlotBytes, 0);
+        request_a(i * kGgSlotBytes, 1);
+        request_b(i * kGgSlotBytes, 0);
+        request_b(i * kGgSlotBytes, 1);
+    }
+    __builtin_amdgcn_s_waitcnt(kGgWait<16, 15>);  // vmcnt(16): all but the four youngest half-stages
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    read_b(B0, 0);
+    MV_GG_STAMP_AT(1);
+    // Two wave groups, one barrier apart: while the waves of group 0 (wr = 0, one per SIMD) multiply, those of group 1
+    // issue their fragment reads and DMA requests, and vice versa -- every part of the loop is closed by a barrier.
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+    int s0 = 0;
+#if defined(MV_GG_ABL) && (MV_GG_ABL & 64)  // timing-only: bit 6 = no K loop (prologue + epilogue only)
+    for (int t = 0; t < 0; ++t) {
+#else
+    for (int t = 0; t < NK; ++t) {
+#endif
+        const int s1 = next_slot(s0), s2 = next_slot(s1), sp = prev_slot(s0);
+        // phase 0: A0 of (t, 0); make sure (t, 1) has landed; first half of the request for the slot before this one
+        const int req0 = t > 0 && sk < NK ? 1 : 0;
+        wait_dma();
+        read_a(A0, s0);
+        request(req0, sp);
+        bar_then_wait_reads();
+        quad(A0, B0, 0, 0);
+        // phase 1: B1 of (t, 1)
+        read_b(B1, s1);
+        request(2 * req0, sp);
+        bar_then_wait_reads();
+        quad(A0, B1, 0, 1);
+        // phase 2: A1 of (t, 1); make sure (t+1, 0) has landed; (t, 0)'s slot is free: first half of its refill
+        const int req2 = sk < NK ? 1 : 0;
+        wait_dma();
+        read_a(A1, s1);
+        request(req2, s0);
+        bar_then_wait_reads();
+        quad(A1, B0, 1, 0);
+        // phase 3: B0 of (t+1, 0) (past the last K tile: a harmless read of a slot nobody writes any more)
+        read_b(B0, s2);
+        request(2 * req2, s0);
+        bar_then_wait_reads();
+        quad(A1, B1, 1, 1);
+        s0 = s2;
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();  // (group 1 ran one barrier behind)
+    __builtin_amdgcn_s_waitcnt(kGgWait<0, 0>);
+    __builtin_amdgcn_s_barrier();
+    MV_GG_STAMP_AT(2);
+
+    // ---- epilogue: bias, gate, bf16; the [256 n][128 c] tile leaves through LDS in 16-byte units along c
+    const float* bias = p.bias + by * kGgTile + wr * 128;
+#pragma unroll
+    for (int tp = 0; tp < 4; ++tp) {
+        const f32x4 bt = *(const f32x4*)(bias + (2 * tp) * 16 + lg * 4);
+        const f32x4 bs = *(const f32x4*)(bias + (2 * tp + 1) * 16 + lg * 4);
+        const int cl = wr * 64 + tp * 16 + lg * 4;
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+            const int nl = wc * 64 + tn * 16 + lr;
+            const f32x4 tv = acc[2 * tp][tn] + bt;
+            const f32x4 sv = acc[2 * tp + 1][tn] + bs;
+            f32x4 g;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g[j] = gate_act<true>(tv[j], sv[j]);
+            *(unsigned long long*)(smem + nl * kGgOutRS + cl * 2) =
+                ((unsigned long long)pack_bf16(g[2], g[3]) << 32) | pack_bf16(g[0], g[1]);
+        }
+    }
+    __syncthreads();
+    MV_GG_STAMP_AT(3);
+    unsigned short* ob = p.out + (long long)b * p.L * p.Cp + by * 128;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int idx = threadIdx.x + k * 512;
+        const int nl = idx >> 4, u = idx & 15;
+        const int n = n0 + nl;
+        if (n < len) *(u32x4*)(ob + (long long)n * p.Cp + u * 8) = *(const u32x4*)(smem + nl * kGgOutRS + u * 16);
+    }
+    MV_GG_STAMP_AT(4);
+#ifdef MV_GG_STAMP
+    if (threadIdx.x == 0) gg_stamps[(blockIdx.y * gridDim.x + blockIdx.x) & 4095][5] = __builtin_amdgcn_s_memrealtime();
+#endif
+}
+
+#endif  // MV_GATE_GEMM_KERNEL
+
+}  // namespace mv

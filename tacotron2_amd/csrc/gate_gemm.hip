@@ -1,0 +1,58 @@
+// gate_gemm.hip -- launch side of gate_gemm.h (WaveGlow's gated in-layer conv as a 256 x 256 LDS-DMA GEMM).
+#define MV_GATE_GEMM_KERNEL
+#include "common.h"
+#include "gate_gemm.h"
+
+namespace mv {
+
+int init_gate_gemm_attributes() {
+    MV_HIP(hipFuncSetAttribute((const void*)gate_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kGgLds));
+    return MV_OK;
+}
+
+// Shapes the kernel assumes (checked here, on the host, before anything is launched).
+bool gate_gemm_supported(int C, int Cp, int ncond, int ktaps) {
+    return C == Cp && C % 128 == 0 && ncond % kGgBK == 0 && Cp % kGgBK == 0 && ktaps % 2 == 1 && ktaps >= 1 &&
+           ktaps * (Cp / kGgBK) + ncond / kGgBK >= 3;  // (the prologue fills a ring of five half-stages)
+}
+
+static inline uint16_t f2bf(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+int build_gate_gemm_weights(const std::vector<SrcSpec>& srcs, int M, unsigned short** dev) {
+    size_t K = 0;
+    for (const SrcSpec& s : srcs) K += (size_t)s.ktaps * s.C;
+    std::vector<unsigned short> w((size_t)M * K);
+    for (int m = 0; m < M; ++m) {
+        unsigned short* row = &w[(size_t)m * K];
+        size_t k = 0;
+        for (const SrcSpec& s : srcs)
+            for (int tap = 0; tap < s.ktaps; ++tap)
+                for (int c = 0; c < s.C; ++c) row[k++] = f2bf(s.w(m, tap, c));
+    }
+    return upload(w, dev);
+}
+
+int launch_gate_gemm(const GateGemmParams& p, int B, hipStream_t stream) {
+    if (p.K != p.ktaps * p.Cp + p.ncond || p.nx < 1 || p.ny < 1 || B < 1 || (long long)p.ny * kGgTile * p.K * 2 > 0xffffffffll) {
+        set_error("gate_gemm: inconsistent launch (K=%d, nx=%d, ny=%d)", p.K, p.nx, p.ny);
+        return MV_EINVAL;
+    }
+    const unsigned blocks = (unsigned)((p.nx + 7) / 8) * 8u * (unsigned)p.ny;
+    hipLaunchKernelGGL(gate_gemm_kernel, dim3(blocks, (unsigned)B), dim3(512), kGgLds, stream, p);
+    MV_HIP(hipGetLastError());
+    return MV_OK;
+}
+
+}  // namespace mv
+
+#ifdef MV_GG_STAMP
+extern "C" __attribute__((visibility("default"))) int mv_debug_gate_gemm_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mv::gg_stamps), sizeof(unsigned long long) * 4096 * 6);
+}
+#endif

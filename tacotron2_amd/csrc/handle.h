@@ -6,7 +6,7 @@ struct mv_handle_s {
     int kind = 0;  // 1 = HiFi-GAN generator, 2 = WaveGlow, 3 = Tacotron2 Postnet
     int device = 0;
     int precision = MV_PREC_FP32;
-    mv_options opt = {2, 1, 1};  // see mv_default_options
+    mv_options opt = {2, 1, 1, 1};  // see mv_default_options
     mv::Profiler prof;
     virtual ~mv_handle_s() { prof.release(); }
     virtual size_t workspace_bytes(int B, int Tmax) const = 0;

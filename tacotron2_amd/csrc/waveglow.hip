@@ -19,6 +19,7 @@
 // VALU), so the MFMA layer keeps its residual half and there is no skip tensor: see waveglow_build.
 #include <cmath>
 
+#include "gate_gemm.h"
 #include "handle.h"
 
 namespace mv {
@@ -36,12 +37,16 @@ struct WgFlow {
     std::vector<Layer> res_only;
     float* fold_w = nullptr;     // device [n_layers][2*n_half][Cp]
     float* fold_b = nullptr;     // device [2*n_half]: end.bias + end.weight * (sum of the skip biases)
+    // bf16 mode: the in_layers' weights once more as plain [2C][K] bfloat16 matrices for gate_gemm_kernel
+    std::vector<unsigned short*> gg_w;
 };
 
 struct WaveglowHandle : mv_handle_s {
     mv_waveglow_cfg cfg;
     int C = 0, Cp = 0, ncond = 0, melp = 0, n_rem = 0;
     bool fold = false;  // folded skip path (WgFlow)
+    bool gg = false;    // gate_gemm_kernel weights were built (bf16 operand tensors, shapes it supports)
+    unsigned short* zero_row = nullptr;  // device, 256 zero bytes: what gate_gemm_kernel reads outside a sequence
     Layer up;
     std::vector<WgFlow> flows;
     double macs = 0;
@@ -52,11 +57,14 @@ struct WaveglowHandle : mv_handle_s {
             for (auto& l : f.in_layers) free_layer(&l);
             for (auto& l : f.res_skip) free_layer(&l);
             for (auto& l : f.res_only) free_layer(&l);
+            for (unsigned short* p : f.gg_w)
+                if (p) (void)hipFree(p);
             if (f.fold_w) (void)hipFree(f.fold_w);
             if (f.fold_b) (void)hipFree(f.fold_b);
             for (float* p : {f.start_w, f.start_b, f.end_w, f.end_b, f.winv})
                 if (p) (void)hipFree(p);
         }
+        if (zero_row) (void)hipFree(zero_row);
     }
     int hop() const override { return 256; }
     double macs_per_frame() const override { return macs; }
@@ -82,10 +90,11 @@ __global__ __launch_bounds__(256) void wg_noise_kernel(const float* __restrict__
 
 // glow.py:155: H = start(audio_0) (1x1, n_half -> C)
 constexpr int kStartRowsPerThread = 8;
+constexpr int kGgMinBlocks = 192;  // 256 x 256 tiles of a gated conv below which conv_cl_kernel's smaller tiles fill the chip better
 __global__ __launch_bounds__(256) void wg_start_kernel(const float* __restrict__ aud, int ng, int off, int n_half,
                                                        const float* __restrict__ w, const float* __restrict__ bias,
                                                        int C, int Cp, long long rows, void* __restrict__ H, int h16,
-                                                       unsigned short* __restrict__ Hb) {
+                                                       unsigned short* __restrict__ Hb, int Hs) {
     // a thread owns 4 channels (its weights and bias stay in registers) and walks the block's rows
     const int q = Cp / 4;  // float4 units per row; the host launches with 256 % q == 0
     const int c0 = (int)(threadIdx.x % q) * 4;
@@ -109,8 +118,8 @@ __global__ __launch_bounds__(256) void wg_start_kernel(const float* __restrict__
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             v[i] = (wr[i][0] * a[0] + wr[i][1] * a[1] + wr[i][2] * a[2] + wr[i][3] * a[3]) + br[i];
-        st4(H, r * Cp + c0, v, h16);
-        if (Hb) st4(Hb, r * Cp + c0, v, 2);  // the MFMA-operand view of H (see waveglow_infer)
+        st4(H, r * Hs + c0, v, h16);
+        if (Hb) st4(Hb, r * Hs + c0, v, 2);  // the MFMA-operand view of H (see waveglow_infer)
     }
 }
 
@@ -119,7 +128,7 @@ __global__ __launch_bounds__(256) void wg_start_generic_kernel(const float* __re
                                                                const float* __restrict__ w,
                                                                const float* __restrict__ bias, int C, int Cp,
                                                                long long rows, void* __restrict__ H, int h16,
-                                                               unsigned short* __restrict__ Hb) {
+                                                               unsigned short* __restrict__ Hb, int Hs) {
     const int q = Cp / 4;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= rows * q) return;
@@ -137,8 +146,8 @@ __global__ __launch_bounds__(256) void wg_start_generic_kernel(const float* __re
             v[i] = s + bias[c];
         }
     }
-    st4(H, r * Cp + c0, v, h16);
-    if (Hb) st4(Hb, r * Cp + c0, v, 2);  // the MFMA-operand view of H (see waveglow_infer)
+    st4(H, r * Hs + c0, v, h16);
+    if (Hb) st4(Hb, r * Hs + c0, v, 2);  // the MFMA-operand view of H (see waveglow_infer)
 }
 
 // Folded skip path: end(sum_i skip_i(acts_i)) = sum_i (W_end W_skip_i) acts_i + const, so layer i adds
@@ -340,6 +349,12 @@ static int waveglow_build(WaveglowHandle* h, WeightMap& W) {
     char name[160];
     int rc;
     double macs_step = 0;
+    // the gated conv as a 256 x 256 GEMM needs bfloat16 operand tensors (io16) and whole 256-row M blocks
+    h->gg = bf16 && h->opt.io16 && h->opt.wg_gemm != 0 && gate_gemm_supported(C, h->Cp, h->ncond, ks);
+    if (h->gg) {
+        std::vector<unsigned short> z(128, 0);
+        if ((rc = upload(z, &h->zero_row))) return rc;
+    }
     {
         // glow.py:183-185,252-260: ConvTranspose1d(nm, nm, 1024, stride 256) + trim + regroup
         const int K = 1024, u = 256, J = 4;
@@ -472,6 +487,11 @@ static int waveglow_build(WaveglowHandle* h, WeightMap& W) {
             const int wide = bf16 && (2 * C) % 256 == 0 ? 1 : -1;
             if ((rc = build_layer(&f.in_layers[i], {sh, sc}, 2 * C, bias, prec, EPI_GATE, wide))) return rc;
             f.in_layers[i].alg_macs_per_n = (double)2 * C * C * ks + (double)2 * C * h->ncond;
+            if (h->gg) {
+                unsigned short* gw = nullptr;
+                if ((rc = build_gate_gemm_weights({sh, sc}, 2 * C, &gw))) return rc;
+                f.gg_w.push_back(gw);
+            }
 
             const int rsC = i < nl - 1 ? 2 * C : C;
             snprintf(name, sizeof name, "WN.%d.res_skip_layers.%d.weight", k, i);
@@ -575,6 +595,8 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
     // Likewise the residual stream H: it accumulates in float32, and every kernel that updates it also leaves a
     // bfloat16 copy (in the unused half of the ACTS buffer) for the next gated conv to stage by plain copies.
     unsigned short* Hb = opd == 2 ? (unsigned short*)((char*)ACTS + WaveglowHandle::al(bl * Cp * 2)) : nullptr;
+    const int Hs = Cp;  // row stride of H / Hb (a padded stride, 64 unused channels per row against power-of-two spacing
+                        // of gate_gemm_kernel's 128-byte pieces, measured no different: 594 vs 594 audio-s/s)
     // one fold launch per flow over all its layers' activations (needs them all kept: bf16 operand storage)
     const bool fold_batch = h->fold && opd == 2;
     const size_t slot = WaveglowHandle::al(bl * Cp * 2);
@@ -604,7 +626,12 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
         MV_HIP(hipGetLastError());
     }
     int ni = 1;
-    const long long bsC = (long long)L * Cp;
+    const long long bsC = (long long)L * Cp, bsH = (long long)L * Hs;
+    // gate_gemm_kernel works on 256-row tiles, one block per CU: taken when the call has enough of them to fill
+    // the chip (or whenever it can run, wg_gemm = 2); shorter calls keep conv_cl_kernel's 128-row tiles
+    const int gg_nx = (L + kGgTile - 1) / kGgTile;
+    const bool use_gg = h->gg && Hb && opd == 2 &&
+                        (h->opt.wg_gemm == 2 || (long long)B * gg_nx * (2 * h->C / kGgTile) >= kGgMinBlocks);
     for (int k = c.n_flows - 1; k >= 0; --k) {
         const WgFlow& f = h->flows[k];
         {
@@ -613,16 +640,16 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
             if (q <= 256 && 256 % q == 0 && f.n_half <= 4) {
                 const long long rpb = 256 / q * kStartRowsPerThread;
                 hipLaunchKernelGGL(wg_start_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, stream, AUD,
-                                   ng, ng - f.Ck, f.n_half, f.start_w, f.start_b, h->C, Cp, rows, H, io16, Hb);
+                                   ng, ng - f.Ck, f.n_half, f.start_w, f.start_b, h->C, Cp, rows, H, io16, Hb, Hs);
             } else {
                 const long long total = rows * q;
                 hipLaunchKernelGGL(wg_start_generic_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
-                                   AUD, ng, ng - f.Ck, f.n_half, f.start_w, f.start_b, h->C, Cp, rows, H, io16, Hb);
+                                   AUD, ng, ng - f.Ck, f.n_half, f.start_w, f.start_b, h->C, Cp, rows, H, io16, Hb, Hs);
             }
             MV_HIP(hipGetLastError());
         }
         for (int i = 0; i < nl; ++i) {
-            SrcBind sb[2] = {Hb ? SrcBind{Hb, bsC, Cp, spf, 1.0f, 2} : SrcBind{H, bsC, Cp, spf, 1.0f, io16}, {SPECT, (long long)L * h->ncond, h->ncond, spf, 1.0f, opd}};
+            SrcBind sb[2] = {Hb ? SrcBind{Hb, bsH, Hs, spf, 1.0f, 2} : SrcBind{H, bsH, Hs, spf, 1.0f, io16}, {SPECT, (long long)L * h->ncond, h->ncond, spf, 1.0f, opd}};
             LaunchArgs a;
             a.lengths = lengths;
             a.B = B;
@@ -630,7 +657,33 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
             a.n_rows_per_frame = spf;
             void* acts_i = fold_batch && i > 0 ? (void*)(ACTS_REST + (size_t)(i - 1) * slot) : ACTS;
             a.out[0] = ConvOut{acts_i, bsC, 0, (long long)spf * Cp, Cp, ACC_STORE, opd};
-            if ((rc = launch_layer(f.in_layers[i], sb, 2, a, stream, prof))) return rc;
+            if (use_gg) {
+                GateGemmParams g;
+                g.w = f.gg_w[i];
+                g.bias = f.in_layers[i].bias;
+                g.h = Hb;
+                g.cond = (const unsigned short*)SPECT;
+                g.out = (unsigned short*)acts_i;
+                g.zero = h->zero_row;
+                g.lengths = lengths;
+                g.Tmax = Tmax;
+                g.spf = spf;
+                g.L = L;
+                g.Cp = Cp;
+                g.h_stride = Hs;
+                g.ncond = h->ncond;
+                g.ktaps = c.kernel_size;
+                g.dil = 1 << i;
+                g.K = c.kernel_size * Cp + h->ncond;
+                g.nx = gg_nx;
+                g.ny = 2 * h->C / kGgTile;
+                if (prof) prof->begin(stream, "mv::gate_gemm_kernel(mv::GateGemmParams)", f.in_layers[i].alg_macs_per_n * spf);
+                rc = launch_gate_gemm(g, B, stream);
+                if (prof) prof->end(stream);
+                if (rc) return rc;
+            } else if ((rc = launch_layer(f.in_layers[i], sb, 2, a, stream, prof))) {
+                return rc;
+            }
             SrcBind sa{acts_i, bsC, Cp, spf, 1.0f, opd};
             if (h->fold) {
                 const int nout = 2 * f.n_half;
@@ -653,7 +706,7 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
                     r.B = B;
                     r.Tmax = Tmax;
                     r.n_rows_per_frame = spf;
-                    r.out[0] = ConvOut{H, bsC, 0, (long long)spf * Cp, Cp, ACC_ADD, io16, Hb};
+                    r.out[0] = ConvOut{H, bsH, 0, (long long)spf * Hs, Hs, ACC_ADD, io16, Hb};
                     if ((rc = launch_layer(f.res_only[i], &sa, 1, r, stream, prof))) return rc;
                 }
                 continue;
@@ -666,7 +719,7 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
             const int skip_mode = i == 0 ? ACC_STORE : ACC_ADD;
             if (i < nl - 1) {
                 r.split = h->C;
-                r.out[0] = ConvOut{H, bsC, 0, (long long)spf * Cp, Cp, ACC_ADD, io16, Hb};
+                r.out[0] = ConvOut{H, bsH, 0, (long long)spf * Hs, Hs, ACC_ADD, io16, Hb};
                 r.out[1] = ConvOut{SKIP, bsC, 0, (long long)spf * Cp, Cp, skip_mode, io16};
             } else {
                 r.out[0] = ConvOut{SKIP, bsC, 0, (long long)spf * Cp, Cp, skip_mode, io16};
@@ -721,6 +774,7 @@ int mv_waveglow_create(const mv_waveglow_cfg* cfg, const mv_tensor* weights, int
     }
     rc = init_kernel_attributes();
     if (rc) return rc;
+    if ((rc = init_gate_gemm_attributes())) return rc;
     WeightMap W;
     if ((rc = W.load(weights, n_weights))) return rc;
     WaveglowHandle* h = new WaveglowHandle();

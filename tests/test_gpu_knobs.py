@@ -51,8 +51,8 @@ def test_hifigan_bf16_parity_under_options(options, golden_dir):
     assert not y[1, 37 * 256:].any() and not y[2, 5 * 256:].any()
 
 
-@pytest.mark.parametrize("options", [None, {"wg_fold": 0}, {"io16": 0}, {"wg_fold": 0, "io16": 0}],
-                         ids=lambda o: str(o))
+@pytest.mark.parametrize("options", [None, {"wg_fold": 0}, {"io16": 0}, {"wg_fold": 0, "io16": 0}, {"wg_gemm": 2},
+                                     {"wg_gemm": 0}, {"wg_gemm": 2, "wg_fold": 0}], ids=lambda o: str(o))
 @pytest.mark.parametrize("name,c", [("waveglow_c512_T16", 512), ("waveglow_c64_T16", 64)])
 def test_waveglow_bf16_parity_under_options(options, name, c, golden_dir):
     d = np.load(os.path.join(golden_dir, name + ".npz"))
@@ -67,6 +67,34 @@ def test_waveglow_bf16_parity_under_options(options, name, c, golden_dir):
     mel = torch.from_numpy(np.stack([synth.synthetic_mel(T, int(d["mel_seed"]) + b) for b in range(B)])).cuda()
     noise = [torch.from_numpy(n) for n in synth.waveglow_noise(cfg, B, T, int(d["noise_seed"]))]
     assert _snr(d["wav"], m.infer(mel, sigma=float(d["sigma"]), noise=noise).cpu().numpy()) >= 40.0
+
+
+def test_waveglow_gate_gemm_agrees_with_the_conv_kernel():
+    """wg_gemm selects gate_gemm_kernel (256 x 256 LDS-DMA GEMM) or conv_cl_kernel for the gated in-layer conv: the same
+    bf16 operands, fp32 accumulation in another order (which later bf16 roundings amplify, so the two are not bit-equal).
+    Both are held against the library's fp32 mode on a ragged batch whose sequences end inside a 256-row tile, within a
+    dilation's reach of a tile edge, and before the first edge; a wrong row at a sequence or tile edge would cost tens
+    of dB."""
+    cfg = copy.deepcopy(synth.WAVEGLOW_512)
+    B, T, lens = 3, 41, [41, 23, 7]
+    mel = torch.full((B, 80, T), synth.MEL_PAD_VALUE)
+    for b, n in enumerate(lens):
+        mel[b, :, :n] = torch.from_numpy(synth.synthetic_mel(n, 70 + b))
+    noise = [torch.from_numpy(n) for n in synth.waveglow_noise(cfg, B, T, 5)]
+    out = {}
+    for key, prec, opts in (("fp32", "fp32", None), ("conv", "bf16", {"wg_gemm": 0}), ("gemm", "bf16", {"wg_gemm": 2})):
+        m = WaveGlow.remove_weightnorm(WaveGlow(**cfg))
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.waveglow_state(cfg, 3).items()})
+        m.cuda().eval()
+        m.precision = prec
+        m.options = opts
+        out[key] = m.infer(mel.cuda(), sigma=0.666, noise=noise, lengths=lens).cpu().numpy()
+    for b, n in enumerate(lens):
+        ref = out["fp32"][b, :n * 256]
+        s_conv, s_gemm = _snr(ref, out["conv"][b, :n * 256]), _snr(ref, out["gemm"][b, :n * 256])
+        assert s_gemm >= 40.0 and abs(s_gemm - s_conv) <= 3.0, (b, s_conv, s_gemm)
+        assert _snr(out["conv"][b, :n * 256], out["gemm"][b, :n * 256]) >= 45.0, b
+        assert not out["gemm"][b, n * 256:].any()
 
 
 def test_bad_options_are_refused():
