@@ -52,6 +52,13 @@ struct GateGemmParams {
     int h_stride;                // elements per row of h (>= Cp)
     int K;                       // ktaps * Cp + ncond
     int nx, ny;                  // N tiles per sequence, M blocks (= 2C / 256)
+    // Folded skip path (waveglow.hip, waveglow_build): this layer's contribution (W_end W_skip_i) acts_i to the end
+    // conv, formed here from the block's gated tile while it sits in LDS.  fold_w = NULL: not folded here.
+    const unsigned short* fold_w;  // [2 (hi, lo)][16][Cp] bfloat16: the [fold_nout][C] fp32 matrix split in two bf16
+    float* fold_out;               // [ny][B * L][8] float: one partial sum per M block (wg_tail_kernel adds them)
+    long long fold_part_stride;    // elements between two partials (= B * L * 8)
+    int fold_nout;                 // 2 * n_half <= 8 rows used
+    int fold_accumulate;           // 0: store (first layer of a flow), 1: add
 };
 
 constexpr int kGgTile = 256, kGgBK = 64;
@@ -294,6 +301,15 @@ __global__ __launch_bounds__(512) void gate_gemm_kernel(const GateGemmParams p) 
     MV_GG_STAMP_AT(2);
 
     // ---- epilogue: bias, gate, bf16; the [256 n][128 c] tile leaves through LDS in 16-byte units along c
+    // (fold: the A fragments of the 16 x 128 slice of the fold matrix, hi and lo, requested now, used after the tile)
+    u32x4 fw[2][4];
+    if (p.fold_w) {
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                fw[hl][ks] = *(const u32x4*)(p.fold_w + ((long long)(hl * 16 + lr) * p.Cp + by * 128 + ks * 32 + lg * 8));
+    }
     const float* bias = p.bias + by * kGgTile + wr * 128;
 #pragma unroll
     for (int tp = 0; tp < 4; ++tp) {
@@ -314,6 +330,28 @@ __global__ __launch_bounds__(512) void gate_gemm_kernel(const GateGemmParams p) 
     }
     __syncthreads();
     MV_GG_STAMP_AT(3);
+    if (p.fold_w) {
+        // out8[n][m] (+)= sum_c fold[m][c] acts[n][c] over the block's 128 channels: 16 n-tiles, two per wave, as
+        // v_mfma_f32_16x16x32_bf16 with the fold matrix as A (rows >= fold_nout are zero) and the LDS tile as B
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int nl = (wave * 2 + q) * 16 + lr;
+            f32x4 fa = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const u32x4 bq = *(const u32x4*)(smem + nl * kGgOutRS + (ks * 32 + lg * 8) * 2);
+                mma16<true>(fa, fw[0][ks], bq);
+                mma16<true>(fa, fw[1][ks], bq);
+            }
+            // lane: column n = nl, rows m = 4 lg .. 4 lg + 3
+            const int n = n0 + nl;
+            if (lg < 2 && lg * 4 < p.fold_nout && n < len) {
+                float* o = p.fold_out + by * p.fold_part_stride + ((long long)b * p.L + n) * 8 + lg * 4;
+                if (p.fold_accumulate) fa += *(const f32x4*)o;
+                *(f32x4*)o = fa;
+            }
+        }
+    }
     unsigned short* ob = p.out + (long long)b * p.L * p.Cp + by * 128;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {

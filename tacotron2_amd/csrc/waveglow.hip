@@ -39,6 +39,7 @@ struct WgFlow {
     float* fold_b = nullptr;     // device [2*n_half]: end.bias + end.weight * (sum of the skip biases)
     // bf16 mode: the in_layers' weights once more as plain [2C][K] bfloat16 matrices for gate_gemm_kernel
     std::vector<unsigned short*> gg_w;
+    unsigned short* gg_fold = nullptr;  // device [n_layers][2 (hi, lo)][16][Cp] bfloat16: fold_w split for the MFMA
 };
 
 struct WaveglowHandle : mv_handle_s {
@@ -60,6 +61,7 @@ struct WaveglowHandle : mv_handle_s {
             for (unsigned short* p : f.gg_w)
                 if (p) (void)hipFree(p);
             if (f.fold_w) (void)hipFree(f.fold_w);
+            if (f.gg_fold) (void)hipFree(f.gg_fold);
             if (f.fold_b) (void)hipFree(f.fold_b);
             for (float* p : {f.start_w, f.start_b, f.end_w, f.end_b, f.winv})
                 if (p) (void)hipFree(p);
@@ -221,7 +223,8 @@ __global__ __launch_bounds__(256) void wg_tail_kernel(const void* __restrict__ s
                                                       const float* __restrict__ winv, float* __restrict__ aud, int ng,
                                                       const int32_t* __restrict__ lengths, int Tmax, int L,
                                                       int steps_per_frame, const float* __restrict__ noise, int n_early,
-                                                      float sigma, const float* __restrict__ folded) {
+                                                      float sigma, const float* __restrict__ folded, int fold_parts,
+                                                      long long fold_part_stride) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* ws = (float*)smem;  // [2*n_half][Cp]
     const int nout = 2 * n_half;
@@ -239,10 +242,12 @@ __global__ __launch_bounds__(256) void wg_tail_kernel(const void* __restrict__ s
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
     if (valid && folded) {  // the end conv's outputs arrive ready-made (wg_skipfold_kernel); end_b = the folded bias
-        if (part == 0) {
+        // (gate_gemm_kernel leaves one partial sum per M block: the four lane groups take them in turn and the
+        // shuffles below add them up)
+        for (int q = part; q < fold_parts; q += 4) {
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                if (j < nout) acc[j] = folded[((long long)b * L + l) * 8 + j];
+                if (j < nout) acc[j] += folded[q * fold_part_stride + ((long long)b * L + l) * 8 + j];
         }
     } else if (valid) {
         const long long se = ((long long)b * L + l) * Cp;
@@ -283,6 +288,20 @@ __global__ __launch_bounds__(256) void wg_tail_kernel(const void* __restrict__ s
     }
     for (int c = 0; c < Ck; ++c) ar[off + c] = o[c];
     for (int j = 0; j < n_early; ++j) ar[off - n_early + j] = sigma * noise[((long long)b * n_early + j) * L + l];
+}
+
+static inline unsigned short bf16_bits(float x) {  // round to nearest even
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+static inline float bf16_value(unsigned short h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
 }
 
 // Gauss-Jordan with partial pivoting in double.  The reference's W.float().inverse() (glow.py:91) raises on a singular
@@ -534,6 +553,18 @@ static int waveglow_build(WaveglowHandle* h, WeightMap& W) {
         if (fold) {
             std::vector<float> fb(fold_bias.begin(), fold_bias.end());
             if ((rc = upload(fb, &f.fold_b)) || (rc = upload(fold_all, &f.fold_w))) return rc;
+            if (h->gg) {  // the same matrices as (hi, lo) bfloat16 pairs, 16 rows each, for gate_gemm_kernel's epilogue
+                std::vector<unsigned short> g16((size_t)nl * 2 * 16 * h->Cp, 0);
+                for (int i = 0; i < nl; ++i)
+                    for (int j = 0; j < 2 * n_half; ++j)
+                        for (int cc = 0; cc < h->Cp; ++cc) {
+                            const float w = fold_all[((size_t)i * 2 * n_half + j) * h->Cp + cc];
+                            const unsigned short hi = bf16_bits(w);
+                            g16[(((size_t)i * 2 + 0) * 16 + j) * h->Cp + cc] = hi;
+                            g16[(((size_t)i * 2 + 1) * 16 + j) * h->Cp + cc] = bf16_bits(w - bf16_value(hi));
+                        }
+                if ((rc = upload(g16, &f.gg_fold))) return rc;
+            }
         }
         // (executed work: with the folded skip path the res_skip layers cost C*C (+ 2*n_half*C on the VALU) per layer)
         macs_step += (double)n_half * C + (double)h->ncond * 2 * C * nl + (double)nl * 2 * C * C * ks +
@@ -632,6 +663,9 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
     const int gg_nx = (L + kGgTile - 1) / kGgTile;
     const bool use_gg = h->gg && Hb && opd == 2 &&
                         (h->opt.wg_gemm == 2 || (long long)B * gg_nx * (2 * h->C / kGgTile) >= kGgMinBlocks);
+    // ... and with it the folded skip path moves into its epilogue (one partial sum per M block, added by wg_tail_kernel)
+    const bool gg_fold = use_gg && h->fold;
+    const int fold_parts = gg_fold ? 2 * h->C / kGgTile : 1;
     for (int k = c.n_flows - 1; k >= 0; --k) {
         const WgFlow& f = h->flows[k];
         {
@@ -655,7 +689,7 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
             a.B = B;
             a.Tmax = Tmax;
             a.n_rows_per_frame = spf;
-            void* acts_i = fold_batch && i > 0 ? (void*)(ACTS_REST + (size_t)(i - 1) * slot) : ACTS;
+            void* acts_i = fold_batch && !gg_fold && i > 0 ? (void*)(ACTS_REST + (size_t)(i - 1) * slot) : ACTS;
             a.out[0] = ConvOut{acts_i, bsC, 0, (long long)spf * Cp, Cp, ACC_STORE, opd};
             if (use_gg) {
                 GateGemmParams g;
@@ -677,6 +711,11 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
                 g.K = c.kernel_size * Cp + h->ncond;
                 g.nx = gg_nx;
                 g.ny = 2 * h->C / kGgTile;
+                g.fold_w = gg_fold ? f.gg_fold + (size_t)i * 2 * 16 * Cp : nullptr;
+                g.fold_out = (float*)SKIP;
+                g.fold_part_stride = (long long)bl * 8;
+                g.fold_nout = 2 * f.n_half;
+                g.fold_accumulate = i > 0;
                 if (prof) prof->begin(stream, "mv::gate_gemm_kernel(mv::GateGemmParams)", f.in_layers[i].alg_macs_per_n * spf);
                 rc = launch_gate_gemm(g, B, stream);
                 if (prof) prof->end(stream);
@@ -689,7 +728,7 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
                 const int nout = 2 * f.n_half;
                 const long long rows = (long long)B * L;
                 // (rows past a sequence's end hold stale activations: their sums are never read, wg_tail masks them)
-                if (!fold_batch || i == nl - 1) {
+                if (!gg_fold && (!fold_batch || i == nl - 1)) {
                     const int nfold = fold_batch ? nl : 1;
                     if (prof) prof->begin(stream, "mv::wg_skipfold_kernel(void const*, void const*, long long, int, int, int, float const*, int, long long, float*, int)", (double)nfold * nout * h->C * spf);
                     hipLaunchKernelGGL(wg_skipfold_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256),
@@ -733,7 +772,7 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
             hipLaunchKernelGGL(wg_tail_kernel, grid, dim3(256), lds, stream, (const void*)SKIP, io16, Cp, f.end_w,
                                h->fold ? f.fold_b : f.end_b, f.n_half, f.Ck, f.winv, AUD, ng, lengths, Tmax, L, spf,
                                early ? noise[ni] : nullptr, early ? c.n_early_size : 0, sigma,
-                               h->fold ? (const float*)SKIP : nullptr);
+                               h->fold ? (const float*)SKIP : nullptr, fold_parts, (long long)bl * 8);
             MV_HIP(hipGetLastError());
         }
         if (early) ++ni;
