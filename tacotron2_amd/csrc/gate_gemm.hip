@@ -39,7 +39,10 @@ int build_gate_gemm_weights(const std::vector<SrcSpec>& srcs, int M, unsigned sh
 }
 
 int launch_gate_gemm(const GateGemmParams& p, int B, hipStream_t stream) {
-    if (p.K != p.ktaps * p.Cp + p.ncond || p.nx < 1 || p.ny < 1 || B < 1 || (long long)p.ny * kGgTile * p.K * 2 > 0xffffffffll) {
+    const long long row_bytes = 2ll * (p.h_stride > p.ncond ? p.h_stride : p.ncond);
+    if (p.K != p.ktaps * p.Cp + p.ncond || p.nx < 1 || p.ny < 1 || B < 1 || p.h_stride < p.Cp ||
+        (long long)p.ny * kGgTile * p.K * 2 > 0xffffffffll || p.L * row_bytes > 0xffffffffll ||
+        (long long)p.nx * kGgTile < p.L || !p.zero) {
         set_error("gate_gemm: inconsistent launch (K=%d, nx=%d, ny=%d)", p.K, p.nx, p.ny);
         return MV_EINVAL;
     }

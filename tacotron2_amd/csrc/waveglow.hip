@@ -661,7 +661,9 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
     // gate_gemm_kernel works on 256-row tiles, one block per CU: taken when the call has enough of them to fill
     // the chip (or whenever it can run, wg_gemm = 2); shorter calls keep conv_cl_kernel's 128-row tiles
     const int gg_nx = (L + kGgTile - 1) / kGgTile;
-    const bool use_gg = h->gg && Hb && opd == 2 &&
+    // (its per-lane row offsets are 32-bit: a sequence's rows x row bytes must stay below 4 GiB)
+    const bool gg_fits = (long long)L * std::max(Hs, h->ncond) * 2 < (1ll << 32);
+    const bool use_gg = h->gg && Hb && opd == 2 && gg_fits &&
                         (h->opt.wg_gemm == 2 || (long long)B * gg_nx * (2 * h->C / kGgTile) >= kGgMinBlocks);
     // ... and with it the folded skip path moves into its epilogue (one partial sum per M block, added by wg_tail_kernel)
     const bool gg_fold = use_gg && h->fold;
