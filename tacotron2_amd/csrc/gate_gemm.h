@@ -301,6 +301,16 @@ __global__ __launch_bounds__(512) void gate_gemm_kernel(const GateGemmParams p) 
     MV_GG_STAMP_AT(2);
 
     // ---- epilogue: bias, gate, bf16; the [256 n][128 c] tile leaves through LDS in 16-byte units along c
+    // The biases first: they are needed at once, and with them ahead in the queue the loads behind them (the fold
+    // matrix and the running partial sums, a first touch of what the previous layer's launch wrote) stay in flight
+    // under the gate arithmetic.
+    const float* bias = p.bias + by * kGgTile + wr * 128;
+    f32x4 bts[4][2];
+#pragma unroll
+    for (int tp = 0; tp < 4; ++tp) {
+        bts[tp][0] = *(const f32x4*)(bias + (2 * tp) * 16 + lg * 4);
+        bts[tp][1] = *(const f32x4*)(bias + (2 * tp + 1) * 16 + lg * 4);
+    }
     // (fold: the A fragments of the 16 x 128 slice of the fold matrix, hi and lo, requested now, used after the tile)
     u32x4 fw[2][4];
     if (p.fold_w) {
@@ -310,11 +320,24 @@ __global__ __launch_bounds__(512) void gate_gemm_kernel(const GateGemmParams p) 
             for (int ks = 0; ks < 4; ++ks)
                 fw[hl][ks] = *(const u32x4*)(p.fold_w + ((long long)(hl * 16 + lr) * p.Cp + by * 128 + ks * 32 + lg * 8));
     }
-    const float* bias = p.bias + by * kGgTile + wr * 128;
+    // ... and the partial sums this block adds to (layers after a flow's first), so that their latency hides under the
+    // gate arithmetic instead of ending the kernel
+    f32x4 fold_old[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    float* fold_dst[2] = {nullptr, nullptr};
+    if (p.fold_w) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int n = n0 + (wave * 2 + q) * 16 + lr;
+            if (lg < 2 && lg * 4 < p.fold_nout && n < len) {
+                fold_dst[q] = p.fold_out + by * p.fold_part_stride + ((long long)b * p.L + n) * 8 + lg * 4;
+                if (p.fold_accumulate) fold_old[q] = *(const f32x4*)fold_dst[q];
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int tp = 0; tp < 4; ++tp) {
-        const f32x4 bt = *(const f32x4*)(bias + (2 * tp) * 16 + lg * 4);
-        const f32x4 bs = *(const f32x4*)(bias + (2 * tp + 1) * 16 + lg * 4);
+        const f32x4 bt = bts[tp][0], bs = bts[tp][1];
         const int cl = wr * 64 + tp * 16 + lg * 4;
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn) {
@@ -344,12 +367,7 @@ __global__ __launch_bounds__(512) void gate_gemm_kernel(const GateGemmParams p) 
                 mma16<true>(fa, fw[1][ks], bq);
             }
             // lane: column n = nl, rows m = 4 lg .. 4 lg + 3
-            const int n = n0 + nl;
-            if (lg < 2 && lg * 4 < p.fold_nout && n < len) {
-                float* o = p.fold_out + by * p.fold_part_stride + ((long long)b * p.L + n) * 8 + lg * 4;
-                if (p.fold_accumulate) fa += *(const f32x4*)o;
-                *(f32x4*)o = fa;
-            }
+            if (fold_dst[q]) *(f32x4*)fold_dst[q] = fa + fold_old[q];
         }
     }
     unsigned short* ob = p.out + (long long)b * p.L * p.Cp + by * 128;
