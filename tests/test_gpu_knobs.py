@@ -97,6 +97,25 @@ def test_waveglow_gate_gemm_agrees_with_the_conv_kernel():
         assert not out["gemm"][b, n * 256:].any()
 
 
+def test_waveglow_gate_gemm_is_deterministic_at_bench_size():
+    """gate_gemm_kernel hands LDS buffers from DMA requests to fragment reads by counted waits and barriers only; a
+    read that ran ahead of its data would show as run-to-run differences.  25 inferences of the bench utterance (250
+    blocks per launch, one per CU, 96 launches each) must be bit-identical, and so must the ragged batch of 8."""
+    cfg = copy.deepcopy(synth.WAVEGLOW_512)
+    m = WaveGlow.remove_weightnorm(WaveGlow(**cfg))
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.waveglow_state(cfg, 0).items()})
+    m.cuda().eval()
+    m.precision = "bf16"
+    m.options = {"wg_gemm": 2}
+    for B, T, lens, reps in ((1, 500, None, 25), (8, 300, [300, 287, 255, 200, 129, 64, 33, 1], 5)):
+        mel = torch.from_numpy(np.stack([synth.synthetic_mel(T, 1234 + b) for b in range(B)])).cuda()
+        noise = [torch.from_numpy(n).cuda() for n in synth.waveglow_noise(cfg, B, T, 9)]
+        first = m.infer(mel, sigma=0.666, noise=noise, lengths=lens).clone()
+        assert torch.isfinite(first).all()
+        for _ in range(reps - 1):
+            assert torch.equal(m.infer(mel, sigma=0.666, noise=noise, lengths=lens), first)
+
+
 def test_bad_options_are_refused():
     with pytest.raises(_native.MelvocError):
         _native.make_options({"no_such_knob": 1})
