@@ -44,7 +44,9 @@ struct GateGemmParams {
     const unsigned short* h;     // [B][L][h_stride] bfloat16: operand copy of the residual stream (Cp channels used)
     const unsigned short* cond;  // [B][L][ncond] bfloat16: upsampled mel, regrouped
     unsigned short* out;         // [B][L][Cp] bfloat16: gated activations
-    const unsigned short* zero;  // >= 64 zero bfloat16 values, 16-byte aligned (rows outside a sequence)
+    const unsigned short* zero;  // max(Cp, ncond) + 64 zero bfloat16 values, 16-byte aligned, ABOVE h and cond and less than
+                                 // 4 GiB past their bases: a row outside its sequence is read from here through the same
+                                 // scalar base (tensor + K chunk) as the real rows
     const int32_t* lengths;      // frames per sequence (NULL: Tmax)
     int Tmax, spf;               // time steps per frame
     long long L;                 // rows per sequence in h / cond / out (= Tmax * spf)
@@ -136,19 +138,34 @@ __global__ __launch_bounds__(512) void gate_gemm_kernel(const GateGemmParams p) 
         glds16(wk + a_voff[j], la + j * 1024);
 #endif
     };
-    auto request_b = [&](int slot_off, int j) {  // piece j of the B rows; j = 1 also steps the cursor
+    // The activation rows of a request: scalar base (this sequence's H or cond tensor + the K chunk) + one 32-bit offset per
+    // lane, like the weights -- a row outside [0, len) becomes the offset of the zero row from that base.  The four
+    // offsets a lane needs (pieces j = 0, 1 of halves s = 0, 1) change only when the cursor enters another segment, so
+    // a request costs no vector arithmetic.  (Formed per request, as 64-bit addresses with their multiply and selects,
+    // they made an activation request cost its wave 350 cycles against 70 for a weight request -- with the SIMD's
+    // other wave multiplying at the time -- and the K loop 136 k cycles against 84 k with weight requests alone.)
+    unsigned b_voff[2][2];
+    auto open_segment = [&]() {
+        const bool is_h = seg < ktaps;
+        const int shift = is_h ? seg * dil - pad : 0;
+        const unsigned rs = is_h ? rs_h : rs_c;
+        const unsigned zoff = (unsigned)(zb - (is_h ? hb : cb));
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int tt = t0 + 8 * j + 32 * sx + shift;
+                // (a cond row is read for tt = its own time step; outside [0, len) it multiplies nothing that is kept)
+                b_voff[sx][j] = ((unsigned)tt < (unsigned)len ? (unsigned)tt * rs : zoff) + c16[j];
+            }
+    };
+    open_segment();
+    auto request_b = [&](int slot_off, int j, int sx) {  // piece j of the B rows of half sx (= the cursor's); j = 1 steps the cursor
         char* lb = smem + slot_off + kGgHalfBytes + wave * 2048;
         const bool is_h = seg < ktaps;
-        const int shift = (is_h ? seg * dil - pad : 0) + 32 * sh;
-        const unsigned rs = is_h ? rs_h : rs_c;
-        const unsigned long long base = (unsigned long long)(is_h ? hb : cb) + (unsigned)kc * 128u;
-        const int tt = t0 + 8 * j + shift;
-        // (a cond row is read for tt = its own time step; outside [0, len) it multiplies nothing that is kept)
-        const bool valid = (unsigned)tt < (unsigned)len;
-        const unsigned voff = (valid ? (unsigned)tt * rs : 0u) + c16[j];
-        const unsigned long long bs = valid ? base : (unsigned long long)zb;
+        const char* base = (is_h ? hb : cb) + (unsigned)kc * 128u;
 #if !(defined(MV_GG_ABL) && (MV_GG_ABL & 16))
-        glds16((const char*)(bs + voff), lb + j * 1024);
+        glds16(base + b_voff[sx][j], lb + j * 1024);
 #endif
         if (j == 1) {
             const bool tile_done = sh == 1;
@@ -157,6 +174,7 @@ __global__ __launch_bounds__(512) void gate_gemm_kernel(const GateGemmParams p) 
             sk = __builtin_amdgcn_readfirstlane(tile_done ? sk + 1 : sk);
             kc = __builtin_amdgcn_readfirstlane(wrap ? 0 : (tile_done ? kc + 1 : kc));
             seg = __builtin_amdgcn_readfirstlane(wrap ? seg + 1 : seg);
+            if (wrap) open_segment();
         }
     };
     auto next_slot = [](int off) { return off + kGgSlotBytes == kGgLds ? 0 : off + kGgSlotBytes; };
@@ -221,14 +239,16 @@ __global__ __launch_bounds__(512) void gate_gemm_kernel(const GateGemmParams p) 
 #endif
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto request = [&](int req, int slot_off) {  // req 1: the A pieces of the half-stage under the cursor, 2: its B pieces
+    // req 1: the A pieces of the half-stage under the cursor, 2: its B pieces; sx = which half that is (the loop requests
+    // first halves in phases 0 / 1 and second halves in phases 2 / 3)
+    auto request = [&](int req, int slot_off, int sx) {
 #if !(defined(MV_GG_ABL) && (MV_GG_ABL & 1))  // timing-only: bit 0 = no DMA in the K loop
         if (req == 1) {
             request_a(slot_off, 0);
             request_a(slot_off, 1);
         } else if (req == 2) {
-            request_b(slot_off, 0);
-            request_b(slot_off, 1);
+            request_b(slot_off, 0, sx);
+            request_b(slot_off, 1, sx);
         }
 #endif
     };
@@ -251,8 +271,8 @@ __global__ __launch_bounds__(512) void gate_gemm_kernel(const GateGemmParams p) 
     for (int i = 0; i < kGgSlots; ++i) {
         request_a(i * kGgSlotBytes, 0);
         request_a(i * kGgSlotBytes, 1);
-        request_b(i * kGgSlotBytes, 0);
-        request_b(i * kGgSlotBytes, 1);
+        request_b(i * kGgSlotBytes, 0, i & 1);
+        request_b(i * kGgSlotBytes, 1, i & 1);
     }
     __builtin_amdgcn_s_waitcnt(kGgWait<16, 15>);  // vmcnt(16): all but the four youngest half-stages
     __builtin_amdgcn_s_barrier();
@@ -273,24 +293,24 @@ __global__ __launch_bounds__(512) void gate_gemm_kernel(const GateGemmParams p) 
         const int req0 = t > 0 && sk < NK ? 1 : 0;
         wait_dma();
         read_a(A0, s0);
-        request(req0, sp);
+        request(req0, sp, 0);
         bar_then_wait_reads();
         quad(A0, B0, 0, 0);
         // phase 1: B1 of (t, 1)
         read_b(B1, s1);
-        request(2 * req0, sp);
+        request(2 * req0, sp, 0);
         bar_then_wait_reads();
         quad(A0, B1, 0, 1);
         // phase 2: A1 of (t, 1); make sure (t+1, 0) has landed; (t, 0)'s slot is free: first half of its refill
         const int req2 = sk < NK ? 1 : 0;
         wait_dma();
         read_a(A1, s1);
-        request(req2, s0);
+        request(req2, s0, 1);
         bar_then_wait_reads();
         quad(A1, B0, 1, 0);
         // phase 3: B0 of (t+1, 0) (past the last K tile: a harmless read of a slot nobody writes any more)
         read_b(B0, s2);
-        request(2 * req2, s0);
+        request(2 * req2, s0, 1);
         bar_then_wait_reads();
         quad(A1, B1, 1, 1);
         s0 = s2;

@@ -47,7 +47,6 @@ struct WaveglowHandle : mv_handle_s {
     int C = 0, Cp = 0, ncond = 0, melp = 0, n_rem = 0;
     bool fold = false;  // folded skip path (WgFlow)
     bool gg = false;    // gate_gemm_kernel weights were built (bf16 operand tensors, shapes it supports)
-    unsigned short* zero_row = nullptr;  // device, 256 zero bytes: what gate_gemm_kernel reads outside a sequence
     Layer up;
     std::vector<WgFlow> flows;
     double macs = 0;
@@ -66,18 +65,21 @@ struct WaveglowHandle : mv_handle_s {
             for (float* p : {f.start_w, f.start_b, f.end_w, f.end_b, f.winv})
                 if (p) (void)hipFree(p);
         }
-        if (zero_row) (void)hipFree(zero_row);
     }
     int hop() const override { return 256; }
     double macs_per_frame() const override { return macs; }
     static size_t al(size_t bytes) { return (bytes + 255) / 256 * 256; }
+    // one zero row as long as the longer of an H row and a cond row (+ one 128-byte K chunk): gate_gemm_kernel adds
+    // the K chunk's byte offset to the base it shares with the real rows
+    size_t zero_bytes() const { return al((size_t)2 * std::max(Cp, ncond) + 128); }
     size_t workspace_bytes(int B, int Tmax) const override {
         const size_t L = (size_t)Tmax * 256 / cfg.n_group;
         const size_t bl = (size_t)B * L;
         // (folded skip path: every layer's gated activations of a flow are kept, as bfloat16, for the one fold launch
         // at its end -- n_layers - 1 slots beyond the ACTS buffer)
+        // (+ the zero row gate_gemm_kernel reads outside a sequence, see waveglow_infer)
         return al((size_t)B * Tmax * melp * 4) + al(bl * ncond * 4) + 3 * al(bl * Cp * 4) + al(bl * cfg.n_group * 4) +
-               (fold ? (size_t)(cfg.n_layers - 1) * al(bl * Cp * 2) : 0);
+               (fold ? (size_t)(cfg.n_layers - 1) * al(bl * Cp * 2) : 0) + zero_bytes();
     }
 };
 
@@ -370,10 +372,6 @@ static int waveglow_build(WaveglowHandle* h, WeightMap& W) {
     double macs_step = 0;
     // the gated conv as a 256 x 256 GEMM needs bfloat16 operand tensors (io16) and whole 256-row M blocks
     h->gg = bf16 && h->opt.io16 && h->opt.wg_gemm != 0 && gate_gemm_supported(C, h->Cp, h->ncond, ks);
-    if (h->gg) {
-        std::vector<unsigned short> z(128, 0);
-        if ((rc = upload(z, &h->zero_row))) return rc;
-    }
     {
         // glow.py:183-185,252-260: ConvTranspose1d(nm, nm, 1024, stride 256) + trim + regroup
         const int K = 1024, u = 256, J = 4;
@@ -631,6 +629,10 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
     // one fold launch per flow over all its layers' activations (needs them all kept: bf16 operand storage)
     const bool fold_batch = h->fold && opd == 2;
     const size_t slot = WaveglowHandle::al(bl * Cp * 2);
+    // a row of zeros right behind ACTS: gate_gemm_kernel addresses the rows of SPECT and Hb and this zero row (what it
+    // reads outside a sequence) as ONE scalar base + a 32-bit lane offset, so the row sits above both, within 4 GiB
+    unsigned short* ZERO = (unsigned short*)ws;
+    ws += h->zero_bytes();
     char* ACTS_REST = ws;  // slots 1 .. n_layers-1
     if (h->fold) ws += (size_t)(nl - 1) * slot;
     float* AUDW = (float*)ws;
@@ -662,9 +664,11 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
     // the chip (or whenever it can run, wg_gemm = 2); shorter calls keep conv_cl_kernel's 128-row tiles
     const int gg_nx = (L + kGgTile - 1) / kGgTile;
     // (its per-lane row offsets are 32-bit: a sequence's rows x row bytes must stay below 4 GiB)
-    const bool gg_fits = (long long)L * std::max(Hs, h->ncond) * 2 < (1ll << 32);
+    const bool gg_fits = (long long)L * std::max(Hs, h->ncond) * 2 < (1ll << 32) &&
+                         (long long)((char*)ZERO + h->zero_bytes() - (char*)SPECT) < (1ll << 32);
     const bool use_gg = h->gg && Hb && opd == 2 && gg_fits &&
                         (h->opt.wg_gemm == 2 || (long long)B * gg_nx * (2 * h->C / kGgTile) >= kGgMinBlocks);
+    if (use_gg) MV_HIP(hipMemsetAsync(ZERO, 0, h->zero_bytes(), stream));
     // ... and with it the folded skip path moves into its epilogue (one partial sum per M block, added by wg_tail_kernel)
     const bool gg_fold = use_gg && h->fold;
     const int fold_parts = gg_fold ? 2 * h->C / kGgTile : 1;
@@ -700,7 +704,7 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
                 g.h = Hb;
                 g.cond = (const unsigned short*)SPECT;
                 g.out = (unsigned short*)acts_i;
-                g.zero = h->zero_row;
+                g.zero = ZERO;
                 g.lengths = lengths;
                 g.Tmax = Tmax;
                 g.spf = spf;
