@@ -61,13 +61,29 @@ struct GateGemmParams {
     long long fold_part_stride;    // elements between two partials (= B * L * 8)
     int fold_nout;                 // 2 * n_half <= 8 rows used
     int fold_accumulate;           // 0: store (first layer of a flow), 1: add
+    // res_gemm_kernel (the residual 1x1 conv, glow.py:168-173 with the skip half folded away): H += W acts + bias.
+    // There `h` is the gated activations [B][L][Cp] (ktaps = 1, ncond = 0, K = Cp), `out` is unused, and:
+    void* res_h;                   // [B][L][res_stride] float16: the residual stream, updated in place
+    unsigned short* res_hb;        // same indexing, bfloat16: its MFMA-operand copy (what the next gated conv reads)
+    int res_stride;
 };
 
-constexpr int kGgTile = 256, kGgBK = 64;
-constexpr int kGgHalfBytes = 128 * kGgBK * 2;         // 128 rows of one operand, one K tile: 16 KiB
-constexpr int kGgSlotBytes = 2 * kGgHalfBytes;        // a half-stage: A part + B part
+constexpr int kGgTile = 256, kGgBK = 64;              // N tile (time steps), K tile
+constexpr int kGgHalfB = 128 * kGgBK * 2;             // the B rows of a half-stage: 128 rows x one K tile = 16 KiB
 constexpr int kGgSlots = 5;
-constexpr int kGgLds = kGgSlots * kGgSlotBytes;       // 160 KiB: the whole LDS of a CU
+// MTW = 16-row M tiles per wave: 8 for the gated conv (block = 256 gate rows), 4 for the residual conv (128 rows)
+template <int MTW>
+struct GgGeom {
+    static constexpr int BM = 32 * MTW;              // rows of M per block (2 wave rows)
+    static constexpr int HM = MTW / 2;               // M tiles of a wave's m half
+    static constexpr int RW = HM * 16;               // A rows per wave row in a half-stage
+    static constexpr int NA = MTW / 4;               // A pieces (8 rows x 128 B) per wave and half-stage
+    static constexpr int HalfA = 2 * RW * kGgBK * 2; // the A rows of a half-stage
+    static constexpr int Slot = HalfA + kGgHalfB;    // a half-stage: A part + B part
+    static constexpr int Lds = kGgSlots * Slot;      // MTW = 8: 160 KiB, the whole LDS of a CU
+    static constexpr int PerHalf = NA + 2;           // DMA requests per wave and half-stage
+};
+constexpr int kGgLds = GgGeom<8>::Lds;
 constexpr int kGgOutRS = 128 * 2 + 16;                // epilogue tile: 256 rows x 128 channels bf16, padded
 
 // s_waitcnt immediate (gfx9 layout): vmcnt in bits [3:0] and [15:14], lgkmcnt in [11:8], expcnt [6:4] left at "no wait"
@@ -88,7 +104,10 @@ __device__ unsigned long long gg_stamps[4096][6];
 #define MV_GG_STAMP_AT(i)
 #endif
 
-__global__ __launch_bounds__(512) void gate_gemm_kernel(const GateGemmParams p) {
+template <int MTW>
+__device__ __forceinline__ void gemm_ring_body(const GateGemmParams& p) {
+    using G = GgGeom<MTW>;
+    constexpr int HM = G::HM, RW = G::RW, NA = G::NA, kHalfA = G::HalfA, kSlot = G::Slot, kLds = G::Lds;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     MV_GG_STAMP_AT(0);
     // XCD-aware order (as conv_cl_kernel): the ny M blocks of a row tile run back to back on one XCD
@@ -113,10 +132,16 @@ __global__ __launch_bounds__(512) void gate_gemm_kernel(const GateGemmParams p) 
     // local row 16 w + 8 j + (l >> 3), i.e. it fetches source chunk (l & 7) ^ ((row >> 1) & 7) = (l & 7) ^ (4 j + (l >> 4)).
     const int srow = lane >> 3;
     const unsigned c16[2] = {(unsigned)(((lane & 7) ^ (lane >> 4)) * 16), (unsigned)(((lane & 7) ^ (4 + (lane >> 4))) * 16)};
-    const int a_r = (wave >> 2) * 128 + (wave & 3) * 16 + srow;  // tile row of the lane's A piece j, half s: a_r + 8 j + 64 s
-    const int b_r = (wave >> 1) * 64 + (wave & 1) * 16 + srow;   // ... of its B piece: b_r + 8 j + 32 s
-    const unsigned a_row = (unsigned)(by * kGgTile + a_r) * (unsigned)p.K * 2u;
-    const unsigned a_voff[2] = {a_row + c16[0], a_row + 16u * (unsigned)p.K + c16[1]};
+    const int b_r = (wave >> 1) * 64 + (wave & 1) * 16 + srow;   // tile row of the lane's B piece j, half s: b_r + 8 j + 32 s
+    // A piece j of the wave: local row 8 NA w + 8 j + (l >> 3) of the half-stage's 2 RW rows = row r of wave row wr_s
+    unsigned a_voff[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int lrow = wave * 8 * NA + 8 * j + srow;
+        const int wr_s = lrow / RW, r = lrow % RW;
+        const unsigned chunk = (unsigned)(((lane & 7) ^ ((lrow >> 1) & 7)) * 16);
+        a_voff[j] = (unsigned)(by * G::BM + wr_s * 2 * RW + r) * (unsigned)p.K * 2u + chunk;  // (half 1: + a_half)
+    }
     const int t0 = n0 + b_r;
     const char* wbase = (const char*)p.w;
     const char* hb = (const char*)(p.h + (long long)b * p.L * p.h_stride);
@@ -126,14 +151,14 @@ __global__ __launch_bounds__(512) void gate_gemm_kernel(const GateGemmParams p) 
     const int NK = p.ktaps * nkc_h + nkc_c;
     const int pad = (p.ktaps - 1) / 2 * p.dil;
 
-    const unsigned rs_h = (unsigned)p.h_stride * 2u, rs_c = (unsigned)p.ncond * 2u, a_half = 128u * (unsigned)p.K;
+    const unsigned rs_h = (unsigned)p.h_stride * 2u, rs_c = (unsigned)p.ncond * 2u, a_half = (unsigned)(2 * RW) * (unsigned)p.K;
     const int ktaps = p.ktaps, dil = p.dil;
     // wave-uniform cursor of the next half-stage to request: segment (tap of H, or ktaps = the cond tensor), K chunk in
     // it, K tile, half.  A half-stage is requested in two steps of two pieces: its A rows, then its B rows.
     int seg = 0, kc = 0, sk = 0, sh = 0;
     auto request_a = [&](int slot_off, int j) {  // piece j of the A rows
 #if !(defined(MV_GG_ABL) && (MV_GG_ABL & 8))  // timing-only: bit 3 = no A requests, bit 4 = no B requests
-        char* la = smem + slot_off + wave * 2048;
+        char* la = smem + slot_off + wave * (NA * 1024);
         const char* wk = wbase + (unsigned)sk * 128u + (sh ? a_half : 0u);
         glds16(wk + a_voff[j], la + j * 1024);
 #endif
@@ -161,7 +186,7 @@ __global__ __launch_bounds__(512) void gate_gemm_kernel(const GateGemmParams p) 
     };
     open_segment();
     auto request_b = [&](int slot_off, int j, int sx) {  // piece j of the B rows of half sx (= the cursor's); j = 1 steps the cursor
-        char* lb = smem + slot_off + kGgHalfBytes + wave * 2048;
+        char* lb = smem + slot_off + kHalfA + wave * 2048;
         const bool is_h = seg < ktaps;
         const char* base = (is_h ? hb : cb) + (unsigned)kc * 128u;
 #if !(defined(MV_GG_ABL) && (MV_GG_ABL & 16))
@@ -177,30 +202,30 @@ __global__ __launch_bounds__(512) void gate_gemm_kernel(const GateGemmParams p) 
             if (wrap) open_segment();
         }
     };
-    auto next_slot = [](int off) { return off + kGgSlotBytes == kGgLds ? 0 : off + kGgSlotBytes; };
-    auto prev_slot = [](int off) { return off == 0 ? kGgLds - kGgSlotBytes : off - kGgSlotBytes; };
+    auto next_slot = [](int off) { return off + kSlot == kLds ? 0 : off + kSlot; };
+    auto prev_slot = [](int off) { return off == 0 ? kLds - kSlot : off - kSlot; };
 
     // ---- fragment addresses within a half-stage slot
     const int swz0 = (lg ^ (lr >> 1)) * 16;  // chunk lg (k = 0..31) of a row; chunk 4 + lg (k = 32..63) is swz0 ^ 64
-    const char* fa = smem + (wr * 64 + lr) * 128;
-    const char* fb = smem + kGgHalfBytes + (wc * 32 + lr) * 128;
+    const char* fa = smem + (wr * RW + lr) * 128;
+    const char* fb = smem + kHalfA + (wc * 32 + lr) * 128;
 
-    f32x4 acc[8][4];
+    f32x4 acc[MTW][4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < MTW; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    u32x4 A0[4][2], A1[4][2], B0[2][2], B1[2][2];
+    u32x4 A0[HM][2], A1[HM][2], B0[2][2], B1[2][2];
 
 #if defined(MV_GG_ABL) && (MV_GG_ABL & 2)  // timing-only: bit 1 = no fragment reads in the K loop
 #define MV_GG_RD(dst, src) asm volatile("" : "+v"(dst) : "v"(src))
 #else
 #define MV_GG_RD(dst, src) dst = *(const u32x4*)(src)
 #endif
-    auto read_a = [&](u32x4 (&A)[4][2], int slot_off) {
+    auto read_a = [&](u32x4 (&A)[HM][2], int slot_off) {
         const char* base = fa + slot_off;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < HM; ++i) {
             MV_GG_RD(A[i][0], base + i * 2048 + swz0);
             MV_GG_RD(A[i][1], base + i * 2048 + (swz0 ^ 64));
         }
@@ -224,14 +249,14 @@ __global__ __launch_bounds__(512) void gate_gemm_kernel(const GateGemmParams p) 
     };
     // One multiply part: 16 MFMAs and the barrier that ends it.  (The DMA requests stay in the load parts: issued between
     // these MFMAs, with the SIMD's other wave in its load part, each request stalled the pipe ~185 cycles: 86 us against 68.)
-    auto quad = [&](const u32x4 (&A)[4][2], const u32x4 (&Bf)[2][2], int mh, int nh) {
+    auto quad = [&](const u32x4 (&A)[HM][2], const u32x4 (&Bf)[2][2], int mh, int nh) {
         __builtin_amdgcn_s_setprio(kMfmaPrio);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) mma16<true>(acc[mh * 4 + i][nh * 2 + j], A[i][ks], Bf[j][ks]);
+                for (int i = 0; i < HM; ++i) mma16<true>(acc[mh * HM + i][nh * 2 + j], A[i][ks], Bf[j][ks]);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
 #if !(defined(MV_GG_ABL) && (MV_GG_ABL & 4))
@@ -244,8 +269,8 @@ __global__ __launch_bounds__(512) void gate_gemm_kernel(const GateGemmParams p) 
     auto request = [&](int req, int slot_off, int sx) {
 #if !(defined(MV_GG_ABL) && (MV_GG_ABL & 1))  // timing-only: bit 0 = no DMA in the K loop
         if (req == 1) {
-            request_a(slot_off, 0);
-            request_a(slot_off, 1);
+#pragma unroll
+            for (int j = 0; j < NA; ++j) request_a(slot_off, j);
         } else if (req == 2) {
             request_b(slot_off, 0, sx);
             request_b(slot_off, 1, sx);
@@ -253,7 +278,7 @@ __global__ __launch_bounds__(512) void gate_gemm_kernel(const GateGemmParams p) 
 #endif
     };
     // This wave's pieces of the half-stage that a LATER load part reads have landed: in steady state that half-stage is
-    // followed by two younger ones in the wave's request queue (8 pieces); once the cursor has run off the end of K,
+    // followed by two younger ones in the wave's request queue (2 (NA + 2) pieces); once the cursor has run off the end of K,
     // fewer are, and the wave waits for everything.  The wait sits one load part before the first read, so that between
     // the two lies a barrier both wave groups have passed (they run one barrier apart).
     auto wait_dma = [&]() {
@@ -261,7 +286,7 @@ __global__ __launch_bounds__(512) void gate_gemm_kernel(const GateGemmParams p) 
         return;
 #endif
         if (sk < NK)
-            __builtin_amdgcn_s_waitcnt(kGgWait<8, 15>);
+            __builtin_amdgcn_s_waitcnt(kGgWait<2 * G::PerHalf, 15>);
         else
             __builtin_amdgcn_s_waitcnt(kGgWait<0, 15>);
     };
@@ -269,12 +294,12 @@ __global__ __launch_bounds__(512) void gate_gemm_kernel(const GateGemmParams p) 
     // prologue: fill the ring (H >= 6: the host checks K >= 3 K tiles), half-stage 0 landed
 #pragma unroll
     for (int i = 0; i < kGgSlots; ++i) {
-        request_a(i * kGgSlotBytes, 0);
-        request_a(i * kGgSlotBytes, 1);
-        request_b(i * kGgSlotBytes, 0, i & 1);
-        request_b(i * kGgSlotBytes, 1, i & 1);
+#pragma unroll
+        for (int j = 0; j < NA; ++j) request_a(i * kSlot, j);
+        request_b(i * kSlot, 0, i & 1);
+        request_b(i * kSlot, 1, i & 1);
     }
-    __builtin_amdgcn_s_waitcnt(kGgWait<16, 15>);  // vmcnt(16): all but the four youngest half-stages
+    __builtin_amdgcn_s_waitcnt(kGgWait<4 * G::PerHalf, 15>);  // all but the four youngest half-stages
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     read_b(B0, 0);
@@ -320,6 +345,7 @@ __global__ __launch_bounds__(512) void gate_gemm_kernel(const GateGemmParams p) 
     __builtin_amdgcn_s_barrier();
     MV_GG_STAMP_AT(2);
 
+    if constexpr (MTW == 8) {
     // ---- epilogue: bias, gate, bf16; the [256 n][128 c] tile leaves through LDS in 16-byte units along c
     // The biases first: they are needed at once, and with them ahead in the queue the loads behind them (the fold
     // matrix and the running partial sums, a first touch of what the previous layer's launch wrote) stay in flight
@@ -398,11 +424,67 @@ __global__ __launch_bounds__(512) void gate_gemm_kernel(const GateGemmParams p) 
         const int n = n0 + nl;
         if (n < len) *(u32x4*)(ob + (long long)n * p.Cp + u * 8) = *(const u32x4*)(smem + nl * kGgOutRS + u * 16);
     }
+    } else {
+    // ---- epilogue of the residual conv: H[n][m] = f16(H[n][m] + f16(acc + bias)), and its bfloat16 copy.  The old H
+    // rows are requested first (a first touch of what the previous launch wrote), the [256 n][128 m] result tile goes
+    // through LDS as float16 and is combined in 16-byte units along m (8 per thread).
+    char* hrow = (char*)p.res_h + ((long long)b * p.L * p.res_stride + by * 128) * 2;
+    char* hbrow = (char*)p.res_hb + ((long long)b * p.L * p.res_stride + by * 128) * 2;
+    u32x4 hold[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int idx = threadIdx.x + k * 512;
+        const int n = n0 + (idx >> 4), u = idx & 15;
+        hold[k] = u32x4{0u, 0u, 0u, 0u};
+        if (n < len) hold[k] = *(const u32x4*)(hrow + ((long long)n * p.res_stride + u * 8) * 2);
+    }
+    const float* bias = p.bias + by * G::BM + wr * 64;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const f32x4 bv = *(const f32x4*)(bias + mt * 16 + lg * 4);
+        const int ml = wr * 64 + mt * 16 + lg * 4;
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+            const int nl = wc * 64 + tn * 16 + lr;
+            const f32x4 v = acc[mt][tn] + bv;
+            f16x4 hv;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hv[i] = (_Float16)fminf(fmaxf(v[i], -65504.f), 65504.f);
+            *(f16x4*)(smem + nl * kGgOutRS + ml * 2) = hv;
+        }
+    }
+    __syncthreads();
+    MV_GG_STAMP_AT(3);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int idx = threadIdx.x + k * 512;
+        const int nl = idx >> 4, u = idx & 15;
+        const int n = n0 + nl;
+        if (n >= len) continue;
+        const f16x8 r = __builtin_bit_cast(f16x8, *(const u32x4*)(smem + nl * kGgOutRS + u * 16));
+        const f16x8 o = __builtin_bit_cast(f16x8, hold[k]);
+        float y[8];
+        f16x8 hh;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            y[i] = (float)r[i] + (float)o[i];
+            hh[i] = (_Float16)fminf(fmaxf(y[i], -65504.f), 65504.f);
+        }
+        const long long e = ((long long)n * p.res_stride + u * 8) * 2;
+        *(f16x8*)(hrow + e) = hh;
+        *(u32x4*)(hbrow + e) = u32x4{pack_bf16(y[0], y[1]), pack_bf16(y[2], y[3]), pack_bf16(y[4], y[5]), pack_bf16(y[6], y[7])};
+    }
+    }
     MV_GG_STAMP_AT(4);
 #ifdef MV_GG_STAMP
     if (threadIdx.x == 0) gg_stamps[(blockIdx.y * gridDim.x + blockIdx.x) & 4095][5] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
+
+__global__ __launch_bounds__(512) void gate_gemm_kernel(const GateGemmParams p) { gemm_ring_body<8>(p); }
+// The residual 1x1 conv on the same ring: 128 x 256 tiles (4 M blocks x the row tiles: as many blocks as the gated conv)
+__global__ __launch_bounds__(512) void res_gemm_kernel(const GateGemmParams p) { gemm_ring_body<4>(p); }
 
 #endif  // MV_GATE_GEMM_KERNEL
 

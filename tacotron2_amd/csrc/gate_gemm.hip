@@ -7,6 +7,7 @@ namespace mv {
 
 int init_gate_gemm_attributes() {
     MV_HIP(hipFuncSetAttribute((const void*)gate_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kGgLds));
+    MV_HIP(hipFuncSetAttribute((const void*)res_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GgGeom<4>::Lds));
     return MV_OK;
 }
 
@@ -48,6 +49,21 @@ int launch_gate_gemm(const GateGemmParams& p, int B, hipStream_t stream) {
     }
     const unsigned blocks = (unsigned)((p.nx + 7) / 8) * 8u * (unsigned)p.ny;
     hipLaunchKernelGGL(gate_gemm_kernel, dim3(blocks, (unsigned)B), dim3(512), kGgLds, stream, p);
+    MV_HIP(hipGetLastError());
+    return MV_OK;
+}
+
+// The residual 1x1 conv on the same kernel body: M = C rows in blocks of 128, K = Cp, one input (the gated activations).
+int launch_res_gemm(const GateGemmParams& p, int B, hipStream_t stream) {
+    if (p.ktaps != 1 || p.ncond != 0 || p.K != p.Cp || p.Cp % kGgBK != 0 || p.Cp / kGgBK < 3 || p.nx < 1 || p.ny < 1 ||
+        B < 1 || p.h_stride < p.Cp || p.res_stride < p.ny * 128 || p.res_stride % 8 != 0 || !p.res_h || !p.res_hb ||
+        !p.zero || (long long)p.ny * 128 * p.K * 2 > 0xffffffffll || p.L * 2ll * p.h_stride > 0xffffffffll ||
+        (long long)p.nx * kGgTile < p.L) {
+        set_error("res_gemm: inconsistent launch (K=%d, Cp=%d, nx=%d, ny=%d)", p.K, p.Cp, p.nx, p.ny);
+        return MV_EINVAL;
+    }
+    const unsigned blocks = (unsigned)((p.nx + 7) / 8) * 8u * (unsigned)p.ny;
+    hipLaunchKernelGGL(res_gemm_kernel, dim3(blocks, (unsigned)B), dim3(512), GgGeom<4>::Lds, stream, p);
     MV_HIP(hipGetLastError());
     return MV_OK;
 }

@@ -39,6 +39,7 @@ struct WgFlow {
     float* fold_b = nullptr;     // device [2*n_half]: end.bias + end.weight * (sum of the skip biases)
     // bf16 mode: the in_layers' weights once more as plain [2C][K] bfloat16 matrices for gate_gemm_kernel
     std::vector<unsigned short*> gg_w;
+    std::vector<unsigned short*> rg_w;  // the residual halves of res_skip as [C][Cp] bfloat16 for res_gemm_kernel
     unsigned short* gg_fold = nullptr;  // device [n_layers][2 (hi, lo)][16][Cp] bfloat16: fold_w split for the MFMA
 };
 
@@ -58,6 +59,8 @@ struct WaveglowHandle : mv_handle_s {
             for (auto& l : f.res_skip) free_layer(&l);
             for (auto& l : f.res_only) free_layer(&l);
             for (unsigned short* p : f.gg_w)
+                if (p) (void)hipFree(p);
+            for (unsigned short* p : f.rg_w)
                 if (p) (void)hipFree(p);
             if (f.fold_w) (void)hipFree(f.fold_w);
             if (f.gg_fold) (void)hipFree(f.gg_fold);
@@ -545,6 +548,11 @@ static int waveglow_build(WaveglowHandle* h, WeightMap& W) {
                     const int cfg = C % 256 == 0 ? 0 : -1;
                     if ((rc = build_layer(&f.res_only[i], {sa}, C, rbias, MV_PREC_BF16, EPI_LINEAR, cfg))) return rc;
                     f.res_only[i].alg_macs_per_n = (double)C * C;
+                    if (h->gg) {
+                        unsigned short* rw16 = nullptr;
+                        if ((rc = build_gate_gemm_weights({sa}, C, &rw16))) return rc;
+                        f.rg_w.push_back(rw16);
+                    }
                 }
             }
         }
@@ -698,7 +706,7 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
             void* acts_i = fold_batch && !gg_fold && i > 0 ? (void*)(ACTS_REST + (size_t)(i - 1) * slot) : ACTS;
             a.out[0] = ConvOut{acts_i, bsC, 0, (long long)spf * Cp, Cp, ACC_STORE, opd};
             if (use_gg) {
-                GateGemmParams g;
+                GateGemmParams g = {};
                 g.w = f.gg_w[i];
                 g.bias = f.in_layers[i].bias;
                 g.h = Hb;
@@ -745,7 +753,34 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
                     if (prof) prof->end(stream);
                     MV_HIP(hipGetLastError());
                 }
-                if (i < nl - 1) {
+                if (i < nl - 1 && gg_fold && io16) {
+                    // the residual conv on the ring kernel as well (128 x 256 tiles): H (float16) += W acts + b
+                    GateGemmParams g = {};
+                    g.w = f.rg_w[i];
+                    g.bias = f.res_only[i].bias;
+                    g.h = (const unsigned short*)acts_i;
+                    g.cond = (const unsigned short*)acts_i;
+                    g.zero = ZERO;
+                    g.lengths = lengths;
+                    g.Tmax = Tmax;
+                    g.spf = spf;
+                    g.L = L;
+                    g.Cp = Cp;
+                    g.ncond = 0;
+                    g.ktaps = 1;
+                    g.dil = 1;
+                    g.h_stride = Cp;
+                    g.K = Cp;
+                    g.nx = gg_nx;
+                    g.ny = h->C / 128;
+                    g.res_h = H;
+                    g.res_hb = Hb;
+                    g.res_stride = Hs;
+                    if (prof) prof->begin(stream, "mv::res_gemm_kernel(mv::GateGemmParams)", f.res_only[i].alg_macs_per_n * spf);
+                    rc = launch_res_gemm(g, B, stream);
+                    if (prof) prof->end(stream);
+                    if (rc) return rc;
+                } else if (i < nl - 1) {
                     LaunchArgs r;
                     r.lengths = lengths;
                     r.B = B;
