@@ -98,8 +98,14 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_dst) {
 
 #ifdef MV_GG_STAMP  // diagnostic build (tools/gg_stamps.py): shader-clock stamps of block phases, in a buffer of their own
 __device__ unsigned long long gg_stamps[4096][6];
+#ifdef MV_GG_STAMP_RES
+#define MV_GG_STAMPED 4
+#else
+#define MV_GG_STAMPED 8
+#endif
 #define MV_GG_STAMP_AT(i) \
-    if (threadIdx.x == 0) gg_stamps[(blockIdx.y * gridDim.x + blockIdx.x) & 4095][i] = __builtin_amdgcn_s_memtime()
+    if (MTW == MV_GG_STAMPED && threadIdx.x == 0) \
+    gg_stamps[(blockIdx.y * gridDim.x + blockIdx.x) & 4095][i] = __builtin_amdgcn_s_memtime()
 #else
 #define MV_GG_STAMP_AT(i)
 #endif
@@ -120,6 +126,20 @@ __device__ __forceinline__ void gemm_ring_body(const GateGemmParams& p) {
     const int n0 = bx * kGgTile;
     if (n0 >= len) return;
 
+    // residual conv: the block's tile of the old H (a first touch of what the previous launch wrote, 8 x 16 bytes per
+    // thread) is requested before anything else -- the oldest entries of the wave's memory queue, they are back by the
+    // time the first half-stage is, and the epilogue finds them in registers
+    u32x4 hold[MTW == 4 ? 8 : 1];
+    if constexpr (MTW == 4) {
+        const char* hrow0 = (const char*)p.res_h + ((long long)b * p.L * p.res_stride + by * 128) * 2;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int idx = threadIdx.x + k * 512;
+            const int n = n0 + (idx >> 4), u = idx & 15;
+            hold[k] = u32x4{0u, 0u, 0u, 0u};
+            if (n < len) hold[k] = *(const u32x4*)(hrow0 + ((long long)n * p.res_stride + u * 8) * 2);
+        }
+    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -426,18 +446,10 @@ __device__ __forceinline__ void gemm_ring_body(const GateGemmParams& p) {
     }
     } else {
     // ---- epilogue of the residual conv: H[n][m] = f16(H[n][m] + f16(acc + bias)), and its bfloat16 copy.  The old H
-    // rows are requested first (a first touch of what the previous launch wrote), the [256 n][128 m] result tile goes
-    // through LDS as float16 and is combined in 16-byte units along m (8 per thread).
+    // rows were requested when the block started (`hold`), the [256 n][128 m] result tile goes through LDS as float16
+    // and is combined in 16-byte units along m (8 per thread).
     char* hrow = (char*)p.res_h + ((long long)b * p.L * p.res_stride + by * 128) * 2;
     char* hbrow = (char*)p.res_hb + ((long long)b * p.L * p.res_stride + by * 128) * 2;
-    u32x4 hold[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int idx = threadIdx.x + k * 512;
-        const int n = n0 + (idx >> 4), u = idx & 15;
-        hold[k] = u32x4{0u, 0u, 0u, 0u};
-        if (n < len) hold[k] = *(const u32x4*)(hrow + ((long long)n * p.res_stride + u * 8) * 2);
-    }
     const float* bias = p.bias + by * G::BM + wr * 64;
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -478,7 +490,8 @@ __device__ __forceinline__ void gemm_ring_body(const GateGemmParams& p) {
     }
     MV_GG_STAMP_AT(4);
 #ifdef MV_GG_STAMP
-    if (threadIdx.x == 0) gg_stamps[(blockIdx.y * gridDim.x + blockIdx.x) & 4095][5] = __builtin_amdgcn_s_memrealtime();
+    if (MTW == MV_GG_STAMPED && threadIdx.x == 0)
+        gg_stamps[(blockIdx.y * gridDim.x + blockIdx.x) & 4095][5] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
 

@@ -23,6 +23,8 @@ def main():
     rc = _native.lib().mv_debug_gate_gemm_stamps(buf.ctypes.data_as(C.c_void_p))
     assert rc == 0, rc
     st = buf[buf[:, 0] > 0].astype(np.int64)
+    # (the buffer holds the LAST launch of either kernel: the final flow's tail follows its last gated conv, so this is
+    # gate_gemm_kernel; build with -DMV_GG_STAMP_RES to stamp res_gemm_kernel instead)
     d = np.diff(st[:, :5], axis=1)
     names = ["prologue", "K loop", "gate -> LDS", "store"]
     print("blocks", len(st))
