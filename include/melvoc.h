@@ -113,9 +113,10 @@ typedef struct mv_options {
     int io16;    /* MV_PREC_BF16: 1 (default) activations between kernels stored as float16, 0 as float32 */
     int wg_fold; /* WaveGlow, MV_PREC_BF16: 1 (default) skip halves of res_skip folded with the end conv
                     (end(sum_i skip_i) = sum_i (W_end W_skip_i) acts_i), 0 the reference's split (glow.py:168-173) */
-    int wg_gemm; /* WaveGlow, MV_PREC_BF16 with io16: the gated in-layer conv as a 256 x 256 LDS-DMA GEMM
-                  * (gate_gemm_kernel): 1 (default) where the call has enough row tiles to fill the chip,
-                  * 2 always (where the shapes allow it), 0 never (conv_cl_kernel) */
+    int wg_gemm; /* WaveGlow, MV_PREC_BF16 with io16: the gated in-layer conv (+ the folded skip path) and the
+                  * residual 1x1 conv as LDS-DMA ring GEMMs (gate_gemm_kernel, res_gemm_kernel): 1 (default) where
+                  * the call has enough row tiles to fill the chip, 2 always (where the shapes allow it), 0 never
+                  * (conv_cl_kernel + wg_skipfold_kernel) */
 } mv_options;
 MV_API void mv_default_options(mv_options* opt);
 
