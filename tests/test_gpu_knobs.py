@@ -53,7 +53,7 @@ def test_hifigan_bf16_parity_under_options(options, golden_dir):
 
 @pytest.mark.parametrize("options", [None, {"wg_fold": 0}, {"io16": 0}, {"wg_fold": 0, "io16": 0}, {"wg_gemm": 2},
                                      {"wg_gemm": 0}, {"wg_gemm": 2, "wg_fold": 0}], ids=lambda o: str(o))
-@pytest.mark.parametrize("name,c", [("waveglow_c512_T16", 512), ("waveglow_c64_T16", 64)])
+@pytest.mark.parametrize("name,c", [("waveglow_c512_T16", 512), ("waveglow_c256_T64", 256), ("waveglow_c64_T16", 64)])
 def test_waveglow_bf16_parity_under_options(options, name, c, golden_dir):
     d = np.load(os.path.join(golden_dir, name + ".npz"))
     cfg = copy.deepcopy(synth.WAVEGLOW_512)
