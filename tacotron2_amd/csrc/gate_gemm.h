@@ -1,38 +1,39 @@
-// gate_gemm.h -- WaveGlow's gated in-layer convolution as a 256 x 256 tiled GEMM with LDS-DMA staging (gfx950 only).
+// gate_gemm.h -- WaveGlow's two big contractions as tiled GEMMs on an LDS-DMA ring (gfx950 only).
 //
-//   acts[n][c] = tanh(t) * sigmoid(s),   (t, s) = rows (c, C + c) of
-//   in_layers[i](H)[.][n] + cond_layer(spect)[2C i + .][n]                       waveglow/glow.py:33-40,164-171
+// gate_gemm_kernel:   acts[n][c] = tanh(t) * sigmoid(s),   (t, s) = rows (c, C + c) of
+//                     in_layers[i](H)[.][n] + cond_layer(spect)[2C i + .][n]              waveglow/glow.py:33-40,164-171
+//                     (+ in its epilogue this layer's term of the folded skip path, waveglow.hip waveglow_build)
+// res_gemm_kernel:    H[n][.] += res_skip_layers[i][:C] acts[n][.] + bias                  waveglow/glow.py:168-173
 //
-// GEMM view: D[m][n] = sum_k W[m][k] X[n][k];  M = 2C rows in (tanh, sigmoid) 16-row tile pairs, N = time steps of
-// one sequence, K = ktaps x C channels of the residual stream H (tap j reads row n + (j - (ktaps-1)/2) dil, zero
-// outside [0, len)) followed by the n_mel x n_group channels of the upsampled mel.  Both operands are bfloat16 in
-// memory (the weights [M][K] row-major, H / spect channels-last), so a K tile of either one is rows of 128 contiguous
-// bytes and travels global -> LDS by `global_load_lds_dwordx4` without touching a register.
+// GEMM view: D[m][n] = sum_k W[m][k] X[n][k];  N = time steps of one sequence (tiles of 256); for the gated conv M = 2C
+// rows in (tanh, sigmoid) 16-row tile pairs (blocks of 256) and K = ktaps x C channels of the residual stream H (tap j
+// reads row n + (j - (ktaps-1)/2) dil, zero outside [0, len)) followed by the n_mel x n_group channels of the upsampled
+// mel; for the residual conv M = C (blocks of 128) and K = C gated channels.  Both operands are bfloat16 in memory (the
+// weights [M][K] row-major, activations channels-last), so a K tile of either one is rows of 128 contiguous bytes and
+// travels global -> LDS by `global_load_lds_dwordx4` without touching a register.
 //
-// Against `conv_cl_kernel<true,4,8,4,1,EPI_GATE>` (256 x 128 tile, activations staged pass by pass with the block
-// waiting on them, weights streamed L2 -> VGPR by every wave): half the bytes into the CU per FLOP, and the K loop
-// never waits for memory -- tile k+2 is requested right after the barrier that frees its buffer and has a whole K
-// tile of MFMAs (>= 2 k cycles per SIMD) to land.
-//
-// Block: 8 waves as 2 (M) x 4 (N), a wave owns 128 x 64 of the 256 x 256 tile = 8 x 4 accumulator tiles of
-// v_mfma_f32_16x16x32_bf16 (128 registers).
+// Block: 8 waves as 2 (M) x 4 (N); a wave owns (16 MTW) x 64 of the tile = MTW x 4 accumulator tiles of
+// v_mfma_f32_16x16x32_bf16 (MTW = 8: 128 registers; MTW = 4: 64).
 // LDS image: the 16-byte chunk c of row r sits at chunk position c ^ ((r >> 1) & 7) of the row.  The DMA writes
 // lane-linear (base + 16 lane), so the permutation is applied to each lane's SOURCE address; the fragment reads apply
 // the same XOR.  With it the four 16-lane groups of a ds_read_b128 (MI355X LDS: {0-3,12-15,20-27}, ...) each touch
 // 16 distinct 16-byte slots of the 256-byte bank row: conflict-free.
 //
-// K loop.  A wave's tile splits into quadrants (m half, n half); fragments of one m half (8 x ds_read_b128) and of one
-// n half (4) live in registers.  The operands arrive in HALF-STAGES -- for one K tile of 64, the A rows of every
-// wave's m half s and the B rows of every wave's n half s: 32 KiB -- through a ring of five slots (all 160 KiB of LDS):
-// one is being read, one is next, three are in flight (96 KiB per CU: what it takes to keep an L2-served CU at its
-// ~70 GB/s; with two whole-tile buffers and one request per K tile the same loop measured 15 us of 70 waiting on DMA).
-//     P0: read B1  (t, 1)     | MFMA (A0, B0)
-//     P1: read A1  (t, 1)     | MFMA (A0, B1)
-//         hand-over: reads done, own DMA of (t+1, 0) landed [vmcnt(12)], s_barrier; request (t+3, 0) into (t, 1)'s slot
-//     P2: read A0' (t+1, 0)   | MFMA (A1, B0)
-//     P3: read B0' (t+1, 0)   | MFMA (A1, B1)
-//         hand-over: reads done, own DMA of (t+1, 1) landed, s_barrier; request (t+3, 1) into (t+1, 0)'s slot
-// so every fragment read is issued one 16-MFMA phase before its first use and never more than 12 are outstanding.
+// K loop.  A wave's tile splits into quadrants (m half, n half); fragments of one m half and of the two n halves live
+// in registers.  The operands arrive in HALF-STAGES -- for one K tile of 64, the A rows of every wave's m half s and
+// the B rows of every wave's n half s (MTW = 8: 32 KiB) -- through a ring of five slots (all 160 KiB of LDS): one is
+// being read, one is next, the others are in flight.  The two wave rows are two GROUPS that run one barrier apart (waves
+// w and w + 4 share a SIMD): every phase is a load part (DMA requests of the half-stage under the cursor, then this
+// phase's fragment reads) and a multiply part (16 MFMAs), each closed by an s_barrier, so on every SIMD one wave
+// multiplies while the other loads:
+//     phase 0: request A rows of (t+2, 0);  read A0 (t, 0);  wait: own pieces of (t, 1) landed  | MFMA (A0, B0)
+//     phase 1: request B rows of (t+2, 0);  read B1 (t, 1)                                       | MFMA (A0, B1)
+//     phase 2: request A rows of (t+2, 1);  read A1 (t, 1);  wait: own pieces of (t+1, 0) landed | MFMA (A1, B0)
+//     phase 3: request B rows of (t+2, 1);  read B0 (t+1, 0)                                     | MFMA (A1, B1)
+// A wait is a counted vmcnt (the wave issues its pieces in a fixed order) and sits one load part before the first read
+// of that half-stage, so that between the two lies a barrier BOTH groups have passed; a slot is refilled two barriers
+// after its last read.  Without its DMA requests this loop runs at 94 % of the MFMA rate; with them it is paced by their
+// issue (~100 cycles each): DESIGN.md section 4 has the measurements that shaped it.
 #pragma once
 #include "conv_mfma.h"
 
