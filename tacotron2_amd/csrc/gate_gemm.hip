@@ -1,4 +1,4 @@
-// gate_gemm.hip -- launch side of gate_gemm.h (WaveGlow's gated in-layer conv as a 256 x 256 LDS-DMA GEMM).
+// gate_gemm.hip -- launch side of gate_gemm.h (WaveGlow's gated in-layer conv and residual 1x1 conv as ring GEMMs).
 #define MV_GATE_GEMM_KERNEL
 #include "common.h"
 #include "gate_gemm.h"
@@ -39,11 +39,16 @@ int build_gate_gemm_weights(const std::vector<SrcSpec>& srcs, int M, unsigned sh
     return upload(w, dev);
 }
 
+static bool aligned16(const void* a, const void* b, const void* c, const void* d, const void* e) {
+    return (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d | (uintptr_t)e) & 15) == 0;
+}
+
 int launch_gate_gemm(const GateGemmParams& p, int B, hipStream_t stream) {
     const long long row_bytes = 2ll * (p.h_stride > p.ncond ? p.h_stride : p.ncond);
-    if (p.K != p.ktaps * p.Cp + p.ncond || p.nx < 1 || p.ny < 1 || B < 1 || p.h_stride < p.Cp ||
+    if (p.K != p.ktaps * p.Cp + p.ncond || p.nx < 1 || p.ny < 1 || B < 1 || p.h_stride < p.Cp || p.ny * 128 != p.Cp ||
+        p.Cp % kGgBK != 0 || p.ncond % kGgBK != 0 || p.h_stride % 8 != 0 || !aligned16(p.w, p.h, p.cond, p.out, p.zero) ||
         (long long)p.ny * kGgTile * p.K * 2 > 0xffffffffll || p.L * row_bytes > 0xffffffffll ||
-        (long long)p.nx * kGgTile < p.L || !p.zero) {
+        (long long)p.nx * kGgTile < p.L || !p.zero || (p.fold_w && (!p.fold_out || p.fold_nout < 1 || p.fold_nout > 8))) {
         set_error("gate_gemm: inconsistent launch (K=%d, nx=%d, ny=%d)", p.K, p.nx, p.ny);
         return MV_EINVAL;
     }
@@ -56,7 +61,8 @@ int launch_gate_gemm(const GateGemmParams& p, int B, hipStream_t stream) {
 // The residual 1x1 conv on the same kernel body: M = C rows in blocks of 128, K = Cp, one input (the gated activations).
 int launch_res_gemm(const GateGemmParams& p, int B, hipStream_t stream) {
     if (p.ktaps != 1 || p.ncond != 0 || p.K != p.Cp || p.Cp % kGgBK != 0 || p.Cp / kGgBK < 3 || p.nx < 1 || p.ny < 1 ||
-        B < 1 || p.h_stride < p.Cp || p.res_stride < p.ny * 128 || p.res_stride % 8 != 0 || !p.res_h || !p.res_hb ||
+        B < 1 || p.h_stride < p.Cp || p.h_stride % 8 != 0 || p.res_stride < p.ny * 128 || p.res_stride % 8 != 0 ||
+        !p.res_h || !p.res_hb || !aligned16(p.w, p.h, p.res_h, p.res_hb, p.zero) ||
         !p.zero || (long long)p.ny * 128 * p.K * 2 > 0xffffffffll || p.L * 2ll * p.h_stride > 0xffffffffll ||
         (long long)p.nx * kGgTile < p.L) {
         set_error("res_gemm: inconsistent launch (K=%d, Cp=%d, nx=%d, ny=%d)", p.K, p.Cp, p.nx, p.ny);
