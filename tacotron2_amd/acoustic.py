@@ -282,27 +282,60 @@ def _decode_step(dec, memory, pmem, mask, S):
     S["t"].add_(1)
 
 
-def _graph_infer(self, dec, memory, pmem, mask, n_steps, cap, poll):
+_GRAPH_CACHE_MAX = 8  # captured decode steps kept per MelProducer (one per (batch, text length) shape)
+
+
+def _capture_step(dec, memory, pmem, mask, cap_alloc):
+    """Static buffers + one captured decode step for inputs of this shape (capture costs ~0.1 s: warm-up steps on a
+    side stream for library plans and allocator pools, then the capture itself)."""
     dev, B, Lin = memory.device, memory.size(0), memory.size(1)
     z = lambda *d: memory.new_zeros(*d)  # noqa: E731
     out_dim = dec.dim_data * dec.nfs
+    E = {"memory": memory.clone(), "pmem": pmem.clone(), "mask": None if mask is None else mask.clone(),
+         "cap_alloc": cap_alloc}
     S = {"x": z(B, out_dim), "ah": z(B, dec.arnn), "ac": z(B, dec.arnn), "dh": z(B, dec.drnn), "dc": z(B, dec.drnn),
-         "aw": z(B, Lin), "awc": z(B, Lin), "ctx": z(B, dec.emb), "mels": z(cap + 1, B, out_dim), "gates": z(cap + 1, B),
-         "t": torch.zeros(1, dtype=torch.long, device=dev), "cap": torch.full((B,), cap, dtype=torch.int32, device=dev),
-         "done_at": torch.full((B,), cap, dtype=torch.int32, device=dev)}
+         "aw": z(B, Lin), "awc": z(B, Lin), "ctx": z(B, dec.emb), "mels": z(cap_alloc + 1, B, out_dim),
+         "gates": z(cap_alloc + 1, B), "t": torch.zeros(1, dtype=torch.long, device=dev),
+         "cap": torch.full((B,), cap_alloc, dtype=torch.int32, device=dev),
+         "done_at": torch.full((B,), cap_alloc, dtype=torch.int32, device=dev)}
     side = torch.cuda.Stream(dev)
     side.wait_stream(torch.cuda.current_stream(dev))
-    with torch.cuda.stream(side):  # warm-up off the capture (library plans, allocator pools), then rewind the state
+    with torch.cuda.stream(side):
         for _ in range(2):
-            _decode_step(dec, memory, pmem, mask, S)
+            _decode_step(dec, E["memory"], E["pmem"], E["mask"], S)
     torch.cuda.current_stream(dev).wait_stream(side)
-    for k in ("x", "ah", "ac", "dh", "dc", "aw", "awc", "ctx", "t"):
-        S[k].zero_()
-    S["done_at"].fill_(cap)
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
-        _decode_step(dec, memory, pmem, mask, S)
-    # (the capture itself does not execute the step: the state is still the go state)
+        _decode_step(dec, E["memory"], E["pmem"], E["mask"], S)
+    # (the capture itself does not execute the step)
+    E["S"], E["graph"] = S, g
+    return E
+
+
+def _graph_infer(self, dec, memory, pmem, mask, n_steps, cap, poll):
+    """The decode loop as replays of one captured step.  Captures are kept per input shape (batch, text length, dtype,
+    masked or not) with their static buffers, so a driver that pads its buckets to a few shapes pays for a capture
+    once per shape, not once per bucket (tacotron2_amd/do_syn_e2e.py: that was most of its Tacotron2 time)."""
+    dev, B = memory.device, memory.size(0)
+    cache = self.__dict__.setdefault("_graph_cache", {})
+    key = (str(dev), B, memory.size(1), memory.dtype, mask is None)
+    E = cache.get(key)
+    if E is None or E["cap_alloc"] < cap:
+        cache.pop(key, None)
+        while len(cache) >= _GRAPH_CACHE_MAX:
+            cache.pop(next(iter(cache)))  # oldest first
+        E = cache[key] = _capture_step(dec, memory, pmem, mask, (cap + 127) // 128 * 128)
+    else:
+        cache[key] = cache.pop(key)  # most recently used last
+        E["memory"].copy_(memory)
+        E["pmem"].copy_(pmem)
+        if mask is not None:
+            E["mask"].copy_(mask)
+    S, g = E["S"], E["graph"]
+    for k in ("x", "ah", "ac", "dh", "dc", "aw", "awc", "ctx", "t"):  # the go state
+        S[k].zero_()
+    S["cap"].fill_(cap)
+    S["done_at"].fill_(cap)
     steps = 0
     for t in range(cap):
         g.replay()
@@ -314,7 +347,8 @@ def _graph_infer(self, dec, memory, pmem, mask, n_steps, cap, poll):
     frames = (done_at.clamp(max=steps) * dec.nfs).to(torch.int32)
     keep = torch.arange(steps * dec.nfs, device=dev)[None, :] < frames[:, None]
     mel = (mel * keep.unsqueeze(1).to(mel.dtype)).contiguous()
-    return mel, frames, S["gates"][:steps].transpose(0, 1)
+    # (mel is a fresh tensor; the gate trace is copied out of the static buffer the next call overwrites)
+    return mel, frames, S["gates"][:steps].transpose(0, 1).clone()
 
 
 MelProducer._infer_graph = _graph_infer

@@ -88,7 +88,9 @@ def synthesize_shard(producer, postnet, voc, texts, steps, rank=0, world=1, devi
         bk = buckets[bi]
         B = len(bk.indices)
         lin = [len(texts[i]) for i in bk.indices]
-        text = torch.zeros((B, max(lin)), dtype=torch.long)
+        # text padded to a multiple of 32 symbols (masked by the lengths): few distinct decode shapes, so the producer's
+        # captured decode step is reused across buckets
+        text = torch.zeros((B, (max(lin) + 31) // 32 * 32), dtype=torch.long)
         for b, i in enumerate(bk.indices):
             text[b, : lin[b]] = torch.from_numpy(texts[i])
         n_steps = [steps[i] for i in bk.indices]
