@@ -313,8 +313,8 @@ def e2e_record(torch, dev):
     producer = do_syn_e2e.build_producer(dev)
     postnet = do_syn_e2e.build_postnet(dev, "bf16")
     voc = do_syn_batch.build_vocoder("synthetic-hifigan", dev, "bf16")
-    texts, steps = do_syn_e2e.synthetic_texts(512, 1234)
-    do_syn_e2e.synthesize_shard(producer, postnet, voc, texts[:64], [8] * 64, device=dev)  # warm-up
+    texts, steps = do_syn_e2e.synthetic_texts(1024, 1234)
+    do_syn_e2e.synthesize_shard(producer, postnet, voc, texts[:512], [8] * 512, device=dev)  # warm-up
     do_syn_e2e.synthesize_shard(producer, postnet, voc, texts[:2], [max(steps)] * 2, device=dev)
     # first pass: every decode shape of the corpus is captured once (kept by the producer); second pass: a running service
     _, st1 = do_syn_e2e.synthesize_shard(producer, postnet, voc, texts, steps, device=dev)
@@ -325,8 +325,8 @@ def e2e_record(torch, dev):
             "audio_seconds": round(a, 2), "wall_s": round(st["wall"], 3), "tc2_s": round(st["t_tc2"], 3),
             "postnet_s": round(st["t_post"], 4), "vocoder_s": round(st["t_voc"], 4),
             "rtf_tc2": round(st["t_tc2"] / a, 6), "rtf_vocoder": round((st["t_voc"] + st["t_post"]) / a, 6),
-            "workload": "512 synthetic utterances of 24-120 symbols (1.7-10 s), tc2_french.yaml-shaped mel producer in "
-                        "PyTorch-ROCm fp32 (batched decode, <= 64 per bucket, step replayed from a HIP graph captured once per "
+            "workload": "1024 synthetic utterances of 24-120 symbols (1.7-10 s), tc2_french.yaml-shaped mel producer in "
+                        "PyTorch-ROCm fp32 (batched decode, <= 512 per bucket, step replayed from a HIP graph captured once per "
                         "bucket shape, lengths imposed) -> native Postnet -> native HiFi-GAN V1 bf16 -> PCM16, all on the "
                         "device; value = second pass over the corpus, first_pass_value includes the captures"}
 
