@@ -221,6 +221,17 @@ __global__ __launch_bounds__(256) void wg_skipfold_kernel(const void* __restrict
     *o = accumulate ? *o + v : v;
 }
 
+// The start conv of the flow that runs next, fused behind wg_tail_kernel (a row's new state is all it reads).
+struct WgNextStart {
+    const float* w;     // [C][n_half], nullptr = not fused
+    const float* bias;  // [C]
+    int n_half, C;
+    void* H;            // residual stream (float16 / float32 by h16), row stride Hs
+    int h16;
+    unsigned short* Hb;  // its bfloat16 operand copy, or nullptr
+    int Hs;
+};
+
 // glow.py:175 (end), 280-285 (coupling inverse, W^-1), 287-292 (early noise).  One wave per 16 steps:
 // lane = 16*part + step; the 4 parts split the channels of SKIP and are summed with two shuffles.
 __global__ __launch_bounds__(256) void wg_tail_kernel(const void* __restrict__ skip, int skip16, int Cp, const float* __restrict__ end_w,
@@ -229,10 +240,25 @@ __global__ __launch_bounds__(256) void wg_tail_kernel(const void* __restrict__ s
                                                       const int32_t* __restrict__ lengths, int Tmax, int L,
                                                       int steps_per_frame, const float* __restrict__ noise, int n_early,
                                                       float sigma, const float* __restrict__ folded, int fold_parts,
-                                                      long long fold_part_stride) {
+                                                      long long fold_part_stride, WgNextStart nx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* ws = (float*)smem;  // [2*n_half][Cp]
+    float* st = ws + 2 * n_half * Cp;  // [64][8]: the block's rows of the new flow state, for the next flow's start conv
     const int nout = 2 * n_half;
+    // the next flow's start conv (nx.w != nullptr): a thread owns 4 channels, as in wg_start_kernel; its weights are
+    // requested first and arrive under the coupling arithmetic
+    const int sq = Cp / 4;
+    const int sc0 = (int)(threadIdx.x % sq) * 4;
+    float swr[4][4], sbr[4];
+    if (nx.w) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = sc0 + i;
+            sbr[i] = c < nx.C ? nx.bias[c] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) swr[i][j] = (c < nx.C && j < nx.n_half) ? nx.w[c * nx.n_half + j] : 0.f;
+        }
+    }
     if (!folded)
         for (int i = threadIdx.x; i < nout * Cp; i += 256) ws[i] = end_w[i];
     __syncthreads();
@@ -272,27 +298,55 @@ __global__ __launch_bounds__(256) void wg_tail_kernel(const void* __restrict__ s
         acc[j] += __shfl_xor(acc[j], 16);
         acc[j] += __shfl_xor(acc[j], 32);
     }
-    if (part != 0 || !live) return;
-    float* ar = aud + ((long long)b * L + l) * ng;
-    const int off = ng - Ck;
-    if (!valid) {
-        for (int c = 0; c < ng; ++c) ar[c] = 0.f;
-        return;
+    if (!nx.w && (part != 0 || !live)) return;
+    float* srow = st + (wave * 16 + (lane & 15)) * 8;  // (the host fuses the start conv only when ng <= 8)
+    if (part == 0 && nx.w) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) srow[c] = 0.f;  // rows past the sequence's end: state 0, H = bias
     }
-    float a[8], o[8];
-    for (int c = 0; c < Ck; ++c) a[c] = ar[off + c];
-    for (int c = 0; c < n_half; ++c) {
-        const float bb = acc[c] + end_b[c];
-        const float s = acc[n_half + c] + end_b[n_half + c];
-        a[n_half + c] = (a[n_half + c] - bb) / expf(s);
+    if (part == 0 && live) {
+        float* ar = aud + ((long long)b * L + l) * ng;
+        const int off = ng - Ck;
+        if (!valid) {
+            for (int c = 0; c < ng; ++c) ar[c] = 0.f;
+        } else {
+            float a[8], o[8];
+            for (int c = 0; c < Ck; ++c) a[c] = ar[off + c];
+            for (int c = 0; c < n_half; ++c) {
+                const float bb = acc[c] + end_b[c];
+                const float s = acc[n_half + c] + end_b[n_half + c];
+                a[n_half + c] = (a[n_half + c] - bb) / expf(s);
+            }
+            for (int r = 0; r < Ck; ++r) {
+                float s = 0.f;
+                for (int c = 0; c < Ck; ++c) s += winv[r * Ck + c] * a[c];
+                o[r] = s;
+            }
+            for (int c = 0; c < Ck; ++c) {
+                ar[off + c] = o[c];
+                if (nx.w) srow[n_early + c] = o[c];
+            }
+            for (int j = 0; j < n_early; ++j) {
+                const float z = sigma * noise[((long long)b * n_early + j) * L + l];
+                ar[off - n_early + j] = z;
+                if (nx.w) srow[j] = z;
+            }
+        }
     }
-    for (int r = 0; r < Ck; ++r) {
-        float s = 0.f;
-        for (int c = 0; c < Ck; ++c) s += winv[r * Ck + c] * a[c];
-        o[r] = s;
+    if (!nx.w) return;
+    // glow.py:155 of the next flow: H = start(audio_0), audio_0 = the first n_half channels of the state just written
+    __syncthreads();
+    for (int it = (int)threadIdx.x / sq; it < 64; it += 256 / sq) {
+        const int l2 = blockIdx.x * 64 + it;
+        if (l2 >= L) break;
+        const float* a = st + it * 8;
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (swr[i][0] * a[0] + swr[i][1] * a[1] + swr[i][2] * a[2] + swr[i][3] * a[3]) + sbr[i];
+        const long long r = (long long)b * L + l2;
+        st4(nx.H, r * nx.Hs + sc0, v, nx.h16);
+        if (nx.Hb) st4(nx.Hb, r * nx.Hs + sc0, v, 2);
     }
-    for (int c = 0; c < Ck; ++c) ar[off + c] = o[c];
-    for (int j = 0; j < n_early; ++j) ar[off - n_early + j] = sigma * noise[((long long)b * n_early + j) * L + l];
 }
 
 static inline unsigned short bf16_bits(float x) {  // round to nearest even
@@ -680,9 +734,10 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
     // ... and with it the folded skip path moves into its epilogue (one partial sum per M block, added by wg_tail_kernel)
     const bool gg_fold = use_gg && h->fold;
     const int fold_parts = gg_fold ? 2 * h->C / kGgTile : 1;
+    bool started = false;  // flow k's start conv already ran behind flow k+1's tail
     for (int k = c.n_flows - 1; k >= 0; --k) {
         const WgFlow& f = h->flows[k];
-        {
+        if (!started) {
             const long long rows = (long long)B * L;
             const int q = Cp / 4;
             if (q <= 256 && 256 % q == 0 && f.n_half <= 4) {
@@ -809,11 +864,22 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
         const bool early = k % c.n_early_every == 0 && k > 0;
         {
             dim3 grid((L + 63) / 64, B);
-            const size_t lds = (size_t)2 * f.n_half * Cp * 4;
+            const size_t lds = (size_t)2 * f.n_half * Cp * 4 + 64 * 8 * 4;
+            // the next flow's start conv rides along where wg_start_kernel's thread layout applies (else its own launch)
+            WgNextStart nxs = {};
+            started = false;
+            if (k > 0) {
+                const WgFlow& g = h->flows[k - 1];
+                const int q = Cp / 4;
+                if (ng <= 8 && q <= 256 && 256 % q == 0 && g.n_half <= 4 && g.Ck == f.Ck + (early ? c.n_early_size : 0)) {
+                    nxs = WgNextStart{g.start_w, g.start_b, g.n_half, h->C, H, io16, Hb, Hs};
+                    started = true;
+                }
+            }
             hipLaunchKernelGGL(wg_tail_kernel, grid, dim3(256), lds, stream, (const void*)SKIP, io16, Cp, f.end_w,
                                h->fold ? f.fold_b : f.end_b, f.n_half, f.Ck, f.winv, AUD, ng, lengths, Tmax, L, spf,
                                early ? noise[ni] : nullptr, early ? c.n_early_size : 0, sigma,
-                               h->fold ? (const float*)SKIP : nullptr, fold_parts, (long long)bl * 8);
+                               h->fold ? (const float*)SKIP : nullptr, fold_parts, (long long)bl * 8, nxs);
             MV_HIP(hipGetLastError());
         }
         if (early) ++ni;
