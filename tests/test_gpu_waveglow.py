@@ -101,13 +101,15 @@ def test_pcm16_and_errors():
         m.infer(mel, sigma=0.1, noise=noise[:2])
 
 
-def test_full_size_bf16_against_fp32_mode():
-    """BASELINE.json configs[2] at full size (512 channels, a 500-frame mel, here two ragged sequences): fp32 mode is
-    pinned to the reference by the goldens above; bf16 mode (bfloat16 operand tensors, folded skip path, fast gate)
-    runs through other kernels and must meet its bar against it per sequence, with zeros past each end."""
+@pytest.mark.parametrize("lengths", [[500, 271], [500, 487, 433, 390, 312, 271, 128, 37]])
+def test_full_size_bf16_against_fp32_mode(lengths):
+    """BASELINE.json configs[2] at full size (512 channels, 500-frame mels; two ragged sequences, and the B = 8 batch
+    of SURVEY section 8d config 3, ragged): fp32 mode is pinned to the reference by the goldens above; bf16 mode
+    (bfloat16 operand tensors, the ring GEMM kernels, folded skip path, fast gate) runs through other kernels and must
+    meet its bar against it per sequence, with zeros past each end."""
     cfg = _cfg(512)
     m = _model(cfg, 0, "fp32")
-    B, T, lengths = 2, 500, [500, 271]
+    B, T = len(lengths), 500
     mel = torch.full((B, 80, T), synth.MEL_PAD_VALUE)
     for b, n in enumerate(lengths):
         mel[b, :, :n] = torch.from_numpy(synth.synthetic_mel(n, 70 + b))
