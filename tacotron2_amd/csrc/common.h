@@ -129,7 +129,7 @@ bool gate_gemm_supported(int C, int Cp, int ncond, int ktaps);
 // (build_gate_gemm_weights below: one layer's weights as the kernel reads them, [M][K] bfloat16 row-major with
 // K = (tap, channel) of srcs[0] followed by the channels of srcs[1])
 int launch_gate_gemm(const GateGemmParams& p, int B, hipStream_t stream);
-int launch_res_gemm(const GateGemmParams& p, int B, hipStream_t stream);
+int launch_res_gemm(const GateGemmParams& p, int B, int bm, hipStream_t stream);
 
 // ---- weight lookup (state-dict names, weight-norm folding) --------------------------------
 struct HostTensor {

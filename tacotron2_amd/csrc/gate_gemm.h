@@ -98,7 +98,7 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_dst) {
 }
 
 #ifdef MV_GG_STAMP  // diagnostic build (tools/gg_stamps.py): shader-clock stamps of block phases, in a buffer of their own
-__device__ unsigned long long gg_stamps[4096][6];
+__device__ unsigned long long gg_stamps[4096][8];  // 0-4 shader clock at phase ends, 5 / 6 the 100 MHz clock at block end / start
 #ifdef MV_GG_STAMP_RES
 #define MV_GG_STAMPED 4
 #else
@@ -111,12 +111,19 @@ __device__ unsigned long long gg_stamps[4096][6];
 #define MV_GG_STAMP_AT(i)
 #endif
 
-template <int MTW>
+// Results leave by non-temporal stores: nothing in this launch reads them again, and lines that are not left dirty in
+// L2 shorten the end of the kernel (+1.0 % at B = 1, +0.5 % at B = 8, same box, alternating).
+#define MV_GG_STORE(ptr, val) __builtin_nontemporal_store(val, ptr)
+template <int MTW, bool RES>
 __device__ __forceinline__ void gemm_ring_body(const GateGemmParams& p) {
     using G = GgGeom<MTW>;
     constexpr int HM = G::HM, RW = G::RW, NA = G::NA, kHalfA = G::HalfA, kSlot = G::Slot, kLds = G::Lds;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     MV_GG_STAMP_AT(0);
+#ifdef MV_GG_STAMP
+    if (MTW == MV_GG_STAMPED && threadIdx.x == 0)
+        gg_stamps[(blockIdx.y * gridDim.x + blockIdx.x) & 4095][6] = __builtin_amdgcn_s_memrealtime();
+#endif
     // XCD-aware order (as conv_cl_kernel): the ny M blocks of a row tile run back to back on one XCD
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int by = slot % p.ny;
@@ -130,17 +137,22 @@ __device__ __forceinline__ void gemm_ring_body(const GateGemmParams& p) {
     // residual conv: the block's tile of the old H (a first touch of what the previous launch wrote, 8 x 16 bytes per
     // thread) is requested before anything else -- the oldest entries of the wave's memory queue, they are back by the
     // time the first half-stage is, and the epilogue finds them in registers
-    u32x4 hold[MTW == 4 ? 8 : 1];
-    if constexpr (MTW == 4) {
-        const char* hrow0 = (const char*)p.res_h + ((long long)b * p.L * p.res_stride + by * 128) * 2;
+    // (the 256-row blocks, RES with MTW = 8, have no registers to park 16 such units through the K loop: they request
+    // them at the head of the epilogue instead, under the conversion of the result tile)
+    constexpr int kResUnits = RES ? 2 * MTW : 1;          // 16-byte units of the [256 n][BM m] float16 tile per thread
+    constexpr int kResUPR = G::BM / 8;                    // ... per row
+    u32x4 hold[kResUnits];
+    auto request_old_h = [&]() {
+        const char* hrow0 = (const char*)p.res_h + ((long long)b * p.L * p.res_stride + by * G::BM) * 2;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < kResUnits; ++k) {
             const int idx = threadIdx.x + k * 512;
-            const int n = n0 + (idx >> 4), u = idx & 15;
+            const int n = n0 + idx / kResUPR, u = idx % kResUPR;
             hold[k] = u32x4{0u, 0u, 0u, 0u};
             if (n < len) hold[k] = *(const u32x4*)(hrow0 + ((long long)n * p.res_stride + u * 8) * 2);
         }
-    }
+    };
+    if constexpr (RES && MTW == 4) request_old_h();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -370,7 +382,7 @@ __device__ __forceinline__ void gemm_ring_body(const GateGemmParams& p) {
     __builtin_amdgcn_s_barrier();
     MV_GG_STAMP_AT(2);
 
-    if constexpr (MTW == 8) {
+    if constexpr (!RES) {
     // ---- epilogue: bias, gate, bf16; the [256 n][128 c] tile leaves through LDS in 16-byte units along c
     // The biases first: they are needed at once, and with them ahead in the queue the loads behind them (the fold
     // matrix and the running partial sums, a first touch of what the previous layer's launch wrote) stay in flight
@@ -447,20 +459,22 @@ __device__ __forceinline__ void gemm_ring_body(const GateGemmParams& p) {
         const int idx = threadIdx.x + k * 512;
         const int nl = idx >> 4, u = idx & 15;
         const int n = n0 + nl;
-        if (n < len) *(u32x4*)(ob + (long long)n * p.Cp + u * 8) = *(const u32x4*)(smem + nl * kGgOutRS + u * 16);
+        if (n < len) MV_GG_STORE((u32x4*)(ob + (long long)n * p.Cp + u * 8), *(const u32x4*)(smem + nl * kGgOutRS + u * 16));
     }
     } else {
     // ---- epilogue of the residual conv: H[n][m] = f16(H[n][m] + f16(acc + bias)), and its bfloat16 copy.  The old H
-    // rows were requested when the block started (`hold`), the [256 n][128 m] result tile goes through LDS as float16
-    // and is combined in 16-byte units along m (8 per thread).
-    char* hrow = (char*)p.res_h + ((long long)b * p.L * p.res_stride + by * 128) * 2;
-    char* hbrow = (char*)p.res_hb + ((long long)b * p.L * p.res_stride + by * 128) * 2;
-    const float* bias = p.bias + by * G::BM + wr * 64;
+    // rows were requested when the block started (`hold`; by the 256-row blocks just now), the [256 n][BM m] result
+    // tile goes through LDS as float16 and is combined in 16-byte units along m.
+    constexpr int kRS = G::BM * 2 + 16;  // padded row of the tile (bank-conflict-free 8-byte writes, 16-byte reads)
+    if constexpr (MTW == 8) request_old_h();
+    char* hrow = (char*)p.res_h + ((long long)b * p.L * p.res_stride + by * G::BM) * 2;
+    char* hbrow = (char*)p.res_hb + ((long long)b * p.L * p.res_stride + by * G::BM) * 2;
+    const float* bias = p.bias + by * G::BM + wr * (16 * MTW);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+    for (int mt = 0; mt < MTW; ++mt) {
         const f32x4 bv = *(const f32x4*)(bias + mt * 16 + lg * 4);
-        const int ml = wr * 64 + mt * 16 + lg * 4;
+        const int ml = wr * (16 * MTW) + mt * 16 + lg * 4;
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn) {
             const int nl = wc * 64 + tn * 16 + lr;
@@ -468,18 +482,18 @@ __device__ __forceinline__ void gemm_ring_body(const GateGemmParams& p) {
             f16x4 hv;
 #pragma unroll
             for (int i = 0; i < 4; ++i) hv[i] = (_Float16)fminf(fmaxf(v[i], -65504.f), 65504.f);
-            *(f16x4*)(smem + nl * kGgOutRS + ml * 2) = hv;
+            *(f16x4*)(smem + nl * kRS + ml * 2) = hv;
         }
     }
     __syncthreads();
     MV_GG_STAMP_AT(3);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < kResUnits; ++k) {
         const int idx = threadIdx.x + k * 512;
-        const int nl = idx >> 4, u = idx & 15;
+        const int nl = idx / kResUPR, u = idx % kResUPR;
         const int n = n0 + nl;
         if (n >= len) continue;
-        const f16x8 r = __builtin_bit_cast(f16x8, *(const u32x4*)(smem + nl * kGgOutRS + u * 16));
+        const f16x8 r = __builtin_bit_cast(f16x8, *(const u32x4*)(smem + nl * kRS + u * 16));
         const f16x8 o = __builtin_bit_cast(f16x8, hold[k]);
         float y[8];
         f16x8 hh;
@@ -489,8 +503,8 @@ __device__ __forceinline__ void gemm_ring_body(const GateGemmParams& p) {
             hh[i] = (_Float16)fminf(fmaxf(y[i], -65504.f), 65504.f);
         }
         const long long e = ((long long)n * p.res_stride + u * 8) * 2;
-        *(f16x8*)(hrow + e) = hh;
-        *(u32x4*)(hbrow + e) = u32x4{pack_bf16(y[0], y[1]), pack_bf16(y[2], y[3]), pack_bf16(y[4], y[5]), pack_bf16(y[6], y[7])};
+        MV_GG_STORE((f16x8*)(hrow + e), hh);
+        MV_GG_STORE((u32x4*)(hbrow + e), (u32x4{pack_bf16(y[0], y[1]), pack_bf16(y[2], y[3]), pack_bf16(y[4], y[5]), pack_bf16(y[6], y[7])}));
     }
     }
     MV_GG_STAMP_AT(4);
@@ -500,9 +514,12 @@ __device__ __forceinline__ void gemm_ring_body(const GateGemmParams& p) {
 #endif
 }
 
-__global__ __launch_bounds__(512) void gate_gemm_kernel(const GateGemmParams p) { gemm_ring_body<8>(p); }
+__global__ __launch_bounds__(512) void gate_gemm_kernel(const GateGemmParams p) { gemm_ring_body<8, false>(p); }
 // The residual 1x1 conv on the same ring: 128 x 256 tiles (4 M blocks x the row tiles: as many blocks as the gated conv)
-__global__ __launch_bounds__(512) void res_gemm_kernel(const GateGemmParams p) { gemm_ring_body<4>(p); }
+__global__ __launch_bounds__(512) void res_gemm_kernel(const GateGemmParams p) { gemm_ring_body<4, true>(p); }
+// ... and on 256 x 256 tiles, for calls with enough row tiles to fill the chip with those (a third fewer operand bytes
+// per multiply-add: the residual conv is bound by what a CU can pull in)
+__global__ __launch_bounds__(512) void res_gemm256_kernel(const GateGemmParams p) { gemm_ring_body<8, true>(p); }
 
 #endif  // MV_GATE_GEMM_KERNEL
 

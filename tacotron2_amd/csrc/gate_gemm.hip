@@ -8,6 +8,7 @@ namespace mv {
 int init_gate_gemm_attributes() {
     MV_HIP(hipFuncSetAttribute((const void*)gate_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kGgLds));
     MV_HIP(hipFuncSetAttribute((const void*)res_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GgGeom<4>::Lds));
+    MV_HIP(hipFuncSetAttribute((const void*)res_gemm256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kGgLds));
     return MV_OK;
 }
 
@@ -58,18 +59,22 @@ int launch_gate_gemm(const GateGemmParams& p, int B, hipStream_t stream) {
     return MV_OK;
 }
 
-// The residual 1x1 conv on the same kernel body: M = C rows in blocks of 128, K = Cp, one input (the gated activations).
-int launch_res_gemm(const GateGemmParams& p, int B, hipStream_t stream) {
-    if (p.ktaps != 1 || p.ncond != 0 || p.K != p.Cp || p.Cp % kGgBK != 0 || p.Cp / kGgBK < 3 || p.nx < 1 || p.ny < 1 ||
-        B < 1 || p.h_stride < p.Cp || p.h_stride % 8 != 0 || p.res_stride < p.ny * 128 || p.res_stride % 8 != 0 ||
-        !p.res_h || !p.res_hb || !aligned16(p.w, p.h, p.res_h, p.res_hb, p.zero) ||
-        !p.zero || (long long)p.ny * 128 * p.K * 2 > 0xffffffffll || p.L * 2ll * p.h_stride > 0xffffffffll ||
-        (long long)p.nx * kGgTile < p.L) {
-        set_error("res_gemm: inconsistent launch (K=%d, Cp=%d, nx=%d, ny=%d)", p.K, p.Cp, p.nx, p.ny);
+// The residual 1x1 conv on the same kernel body: M = C rows in blocks of `bm` = 128 or 256, K = Cp, one input (the gated
+// activations).
+int launch_res_gemm(const GateGemmParams& p, int B, int bm, hipStream_t stream) {
+    if ((bm != 128 && bm != 256) || p.ktaps != 1 || p.ncond != 0 || p.K != p.Cp || p.Cp % kGgBK != 0 ||
+        p.Cp / kGgBK < 3 || p.nx < 1 || p.ny < 1 || B < 1 || p.h_stride < p.Cp || p.h_stride % 8 != 0 ||
+        p.res_stride < p.ny * bm || p.res_stride % 8 != 0 || !p.res_h || !p.res_hb ||
+        !aligned16(p.w, p.h, p.res_h, p.res_hb, p.zero) || !p.zero || (long long)p.ny * bm * p.K * 2 > 0xffffffffll ||
+        p.L * 2ll * p.h_stride > 0xffffffffll || (long long)p.nx * kGgTile < p.L) {
+        set_error("res_gemm: inconsistent launch (K=%d, Cp=%d, nx=%d, ny=%d, bm=%d)", p.K, p.Cp, p.nx, p.ny, bm);
         return MV_EINVAL;
     }
     const unsigned blocks = (unsigned)((p.nx + 7) / 8) * 8u * (unsigned)p.ny;
-    hipLaunchKernelGGL(res_gemm_kernel, dim3(blocks, (unsigned)B), dim3(512), GgGeom<4>::Lds, stream, p);
+    if (bm == 128)
+        hipLaunchKernelGGL(res_gemm_kernel, dim3(blocks, (unsigned)B), dim3(512), GgGeom<4>::Lds, stream, p);
+    else
+        hipLaunchKernelGGL(res_gemm256_kernel, dim3(blocks, (unsigned)B), dim3(512), kGgLds, stream, p);
     MV_HIP(hipGetLastError());
     return MV_OK;
 }
@@ -78,6 +83,6 @@ int launch_res_gemm(const GateGemmParams& p, int B, hipStream_t stream) {
 
 #ifdef MV_GG_STAMP
 extern "C" __attribute__((visibility("default"))) int mv_debug_gate_gemm_stamps(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mv::gg_stamps), sizeof(unsigned long long) * 4096 * 6);
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mv::gg_stamps), sizeof(unsigned long long) * 4096 * 8);
 }
 #endif

@@ -221,6 +221,21 @@ __global__ __launch_bounds__(256) void wg_skipfold_kernel(const void* __restrict
     *o = accumulate ? *o + v : v;
 }
 
+// st4 (conv_mfma.h) with non-temporal stores, for results that the storing launch does not read again
+__device__ __forceinline__ void st4_nt(void* base, long long e, const f32x4& v, int f16) {
+    if (f16 == 2) {
+        __builtin_nontemporal_store(((unsigned long long)pack_bf16(v[2], v[3]) << 32) | pack_bf16(v[0], v[1]),
+                                    (unsigned long long*)((unsigned short*)base + e));
+    } else if (f16) {
+        f16x4 h;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h[i] = (_Float16)fminf(fmaxf(v[i], -65504.f), 65504.f);
+        __builtin_nontemporal_store(h, (f16x4*)((_Float16*)base + e));
+    } else {
+        __builtin_nontemporal_store(v, (f32x4*)((float*)base + e));
+    }
+}
+
 // The start conv of the flow that runs next, fused behind wg_tail_kernel (a row's new state is all it reads).
 struct WgNextStart {
     const float* w;     // [C][n_half], nullptr = not fused
@@ -344,8 +359,8 @@ __global__ __launch_bounds__(256) void wg_tail_kernel(const void* __restrict__ s
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = (swr[i][0] * a[0] + swr[i][1] * a[1] + swr[i][2] * a[2] + swr[i][3] * a[3]) + sbr[i];
         const long long r = (long long)b * L + l2;
-        st4(nx.H, r * nx.Hs + sc0, v, nx.h16);
-        if (nx.Hb) st4(nx.Hb, r * nx.Hs + sc0, v, 2);
+        st4_nt(nx.H, r * nx.Hs + sc0, v, nx.h16);
+        if (nx.Hb) st4_nt(nx.Hb, r * nx.Hs + sc0, v, 2);
     }
 }
 
@@ -734,6 +749,8 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
     // ... and with it the folded skip path moves into its epilogue (one partial sum per M block, added by wg_tail_kernel)
     const bool gg_fold = use_gg && h->fold;
     const int fold_parts = gg_fold ? 2 * h->C / kGgTile : 1;
+    // the residual conv's M block: 256 rows when the call has enough row tiles to fill the chip with those, else 128
+    const int res_bm = h->C % 256 == 0 && (long long)B * gg_nx * (h->C / 256) >= kGgMinBlocks ? 256 : 128;
     bool started = false;  // flow k's start conv already ran behind flow k+1's tail
     for (int k = c.n_flows - 1; k >= 0; --k) {
         const WgFlow& f = h->flows[k];
@@ -827,12 +844,12 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
                     g.h_stride = Cp;
                     g.K = Cp;
                     g.nx = gg_nx;
-                    g.ny = h->C / 128;
+                    g.ny = h->C / res_bm;
                     g.res_h = H;
                     g.res_hb = Hb;
                     g.res_stride = Hs;
-                    if (prof) prof->begin(stream, "mv::res_gemm_kernel(mv::GateGemmParams)", f.res_only[i].alg_macs_per_n * spf);
-                    rc = launch_res_gemm(g, B, stream);
+                    if (prof) prof->begin(stream, res_bm == 256 ? "mv::res_gemm256_kernel(mv::GateGemmParams)" : "mv::res_gemm_kernel(mv::GateGemmParams)", f.res_only[i].alg_macs_per_n * spf);
+                    rc = launch_res_gemm(g, B, res_bm, stream);
                     if (prof) prof->end(stream);
                     if (rc) return rc;
                 } else if (i < nl - 1) {

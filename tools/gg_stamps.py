@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Block-phase timing of gate_gemm_kernel from a diagnostic build (-DMV_GG_STAMP, loaded through MELVOC_LIB):
 shader-clock stamps at block start / prologue done / K loop done / gate tile in LDS / stored, of the LAST launch.
-usage (GPU box): MELVOC_LIB=abtest/libmelvoc_stamp.so python tools/gg_stamps.py"""
+usage (GPU box): MELVOC_LIB=abtest/libmelvoc_stamp.so python tools/gg_stamps.py [batch]"""
 import ctypes as C
 import os
 import sys
@@ -15,11 +15,12 @@ from tacotron2_amd import _native  # noqa: E402
 
 
 def main():
-    _m, run, *_ = bench.build_model(torch, "waveglow", "bf16", 0, 0, torch.device("cuda:0"))
+    _m, run, *_ = bench.build_model(torch, "waveglow", "bf16", int(sys.argv[1]) if len(sys.argv) > 1 else 0, 0,
+                                     torch.device("cuda:0"))
     for _ in range(3):
         run()
     torch.cuda.synchronize()
-    buf = np.zeros((4096, 6), np.uint64)
+    buf = np.zeros((4096, 8), np.uint64)
     rc = _native.lib().mv_debug_gate_gemm_stamps(buf.ctypes.data_as(C.c_void_p))
     assert rc == 0, rc
     st = buf[buf[:, 0] > 0].astype(np.int64)
@@ -32,6 +33,9 @@ def main():
         print("%-12s median %7.0f  p10 %7.0f  p90 %7.0f cycles" % (n, np.median(d[:, i]), np.percentile(d[:, i], 10), np.percentile(d[:, i], 90)))
     tot = st[:, 4] - st[:, 0]
     print("block total  median %7.0f  max %7.0f cycles" % (np.median(tot), tot.max()))
+    real = (st[:, 5] - st[:, 6]) * 10.0  # ns (the constant 100 MHz clock)
+    print("block wall   median %7.0f  max %7.0f ns -> %.2f GHz shader clock" % (np.median(real), real.max(), np.median(tot) / np.median(real)))
+    print("launch wall  %.0f ns (first block start -> last block end)" % ((st[:, 5].max() - st[:, 6].min()) * 10.0))
     print("first start -> last end: %.0f cycles (shader clocks are per XCD: indicative only)" % (st[:, 4].max() - st[:, 0].min()))
 
 
