@@ -97,6 +97,21 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
+// gate_act<true> (conv_mfma.h) on two values at a time: the multiplies and adds around the three transcendentals as
+// packed fp32 operations (the epilogue is VALU-bound: 64 gates per lane, two waves per SIMD)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gate_act_x2(f32x2 t, f32x2 s) {
+    constexpr float kLog2e = 1.44269504088896341f;
+    t[0] = __builtin_amdgcn_fmed3f(t[0], -15.f, 15.f);
+    t[1] = __builtin_amdgcn_fmed3f(t[1], -15.f, 15.f);
+    const f32x2 a = t * (2.f * kLog2e), c = s * -kLog2e;
+    const f32x2 e2t = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+    const f32x2 es = {__builtin_amdgcn_exp2f(c[0]), __builtin_amdgcn_exp2f(c[1])};
+    const f32x2 den = (e2t + 1.f) * (es + 1.f);
+    const f32x2 r = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+    return (e2t - 1.f) * r;
+}
+
 #ifdef MV_GG_STAMP  // diagnostic build (tools/gg_stamps.py): shader-clock stamps of block phases, in a buffer of their own
 __device__ unsigned long long gg_stamps[4096][8];  // 0-4 shader clock at phase ends, 5 / 6 the 100 MHz clock at block end / start
 #ifdef MV_GG_STAMP_RES
@@ -427,9 +442,9 @@ __device__ __forceinline__ void gemm_ring_body(const GateGemmParams& p) {
             const int nl = wc * 64 + tn * 16 + lr;
             const f32x4 tv = acc[2 * tp][tn] + bt;
             const f32x4 sv = acc[2 * tp + 1][tn] + bs;
-            f32x4 g;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) g[j] = gate_act<true>(tv[j], sv[j]);
+            const f32x2 g01 = gate_act_x2(f32x2{tv[0], tv[1]}, f32x2{sv[0], sv[1]});
+            const f32x2 g23 = gate_act_x2(f32x2{tv[2], tv[3]}, f32x2{sv[2], sv[3]});
+            const f32x4 g = {g01[0], g01[1], g23[0], g23[1]};
             *(unsigned long long*)(smem + nl * kGgOutRS + cl * 2) =
                 ((unsigned long long)pack_bf16(g[2], g[3]) << 32) | pack_bf16(g[0], g[1]);
         }
