@@ -115,8 +115,10 @@ typedef struct mv_options {
                     (end(sum_i skip_i) = sum_i (W_end W_skip_i) acts_i), 0 the reference's split (glow.py:168-173) */
     int wg_gemm; /* WaveGlow, MV_PREC_BF16 with io16: the gated in-layer conv (+ the folded skip path) and the
                   * residual 1x1 conv as LDS-DMA ring GEMMs (gate_gemm_kernel, res_gemm_kernel): 1 (default) where
-                  * the call has enough row tiles to fill the chip, 2 always (where the shapes allow it), 0 never
-                  * (conv_cl_kernel + wg_skipfold_kernel) */
+                  * the call has enough row tiles to fill the chip (the residual conv then on 128- or 256-row blocks
+                  * by the number of tiles), 2 always (where the shapes allow it), 3 always and with the 256-row
+                  * residual blocks wherever the channel count allows them, 0 never (conv_cl_kernel +
+                  * wg_skipfold_kernel) */
 } mv_options;
 MV_API void mv_default_options(mv_options* opt);
 

@@ -15,8 +15,8 @@ int resolve_options(const mv_options* in, mv_options* out) {
     mv_default_options(out);
     if (!in) return MV_OK;
     if (in->fuse < 0 || in->fuse > 2 || in->io16 < 0 || in->io16 > 1 || in->wg_fold < 0 || in->wg_fold > 1 ||
-        in->wg_gemm < 0 || in->wg_gemm > 2) {
-        set_error("mv_options: fuse and wg_gemm must be 0..2, io16 and wg_fold 0 or 1 (got %d, %d, %d, %d)", in->fuse,
+        in->wg_gemm < 0 || in->wg_gemm > 3) {
+        set_error("mv_options: fuse must be 0..2, wg_gemm 0..3, io16 and wg_fold 0 or 1 (got %d, %d, %d, %d)", in->fuse,
                   in->io16, in->wg_fold, in->wg_gemm);
         return MV_EINVAL;
     }

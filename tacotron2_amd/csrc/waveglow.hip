@@ -738,19 +738,20 @@ static int waveglow_infer(WaveglowHandle* h, const float* mel, const int32_t* le
     int ni = 1;
     const long long bsC = (long long)L * Cp, bsH = (long long)L * Hs;
     // gate_gemm_kernel works on 256-row tiles, one block per CU: taken when the call has enough of them to fill
-    // the chip (or whenever it can run, wg_gemm = 2); shorter calls keep conv_cl_kernel's 128-row tiles
+    // the chip (or whenever it can run, wg_gemm >= 2); shorter calls keep conv_cl_kernel's 128-row tiles
     const int gg_nx = (L + kGgTile - 1) / kGgTile;
     // (its per-lane row offsets are 32-bit: a sequence's rows x row bytes must stay below 4 GiB)
     const bool gg_fits = (long long)L * std::max(Hs, h->ncond) * 2 < (1ll << 32) &&
                          (long long)((char*)ZERO + h->zero_bytes() - (char*)SPECT) < (1ll << 32);
     const bool use_gg = h->gg && Hb && opd == 2 && gg_fits &&
-                        (h->opt.wg_gemm == 2 || (long long)B * gg_nx * (2 * h->C / kGgTile) >= kGgMinBlocks);
+                        (h->opt.wg_gemm >= 2 || (long long)B * gg_nx * (2 * h->C / kGgTile) >= kGgMinBlocks);
     if (use_gg) MV_HIP(hipMemsetAsync(ZERO, 0, h->zero_bytes(), stream));
     // ... and with it the folded skip path moves into its epilogue (one partial sum per M block, added by wg_tail_kernel)
     const bool gg_fold = use_gg && h->fold;
     const int fold_parts = gg_fold ? 2 * h->C / kGgTile : 1;
     // the residual conv's M block: 256 rows when the call has enough row tiles to fill the chip with those, else 128
-    const int res_bm = h->C % 256 == 0 && (long long)B * gg_nx * (h->C / 256) >= kGgMinBlocks ? 256 : 128;
+    const int res_bm =
+        h->C % 256 == 0 && (h->opt.wg_gemm == 3 || (long long)B * gg_nx * (h->C / 256) >= kGgMinBlocks) ? 256 : 128;
     bool started = false;  // flow k's start conv already ran behind flow k+1's tail
     for (int k = c.n_flows - 1; k >= 0; --k) {
         const WgFlow& f = h->flows[k];

@@ -52,7 +52,7 @@ def test_hifigan_bf16_parity_under_options(options, golden_dir):
 
 
 @pytest.mark.parametrize("options", [None, {"wg_fold": 0}, {"io16": 0}, {"wg_fold": 0, "io16": 0}, {"wg_gemm": 2},
-                                     {"wg_gemm": 0}, {"wg_gemm": 2, "wg_fold": 0}], ids=lambda o: str(o))
+                                     {"wg_gemm": 3}, {"wg_gemm": 0}, {"wg_gemm": 2, "wg_fold": 0}], ids=lambda o: str(o))
 @pytest.mark.parametrize("name,c", [("waveglow_c512_T16", 512), ("waveglow_c256_T64", 256), ("waveglow_c64_T16", 64)])
 def test_waveglow_bf16_parity_under_options(options, name, c, golden_dir):
     d = np.load(os.path.join(golden_dir, name + ".npz"))
@@ -82,7 +82,8 @@ def test_waveglow_gate_gemm_agrees_with_the_conv_kernel():
         mel[b, :, :n] = torch.from_numpy(synth.synthetic_mel(n, 70 + b))
     noise = [torch.from_numpy(n) for n in synth.waveglow_noise(cfg, B, T, 5)]
     out = {}
-    for key, prec, opts in (("fp32", "fp32", None), ("conv", "bf16", {"wg_gemm": 0}), ("gemm", "bf16", {"wg_gemm": 2})):
+    for key, prec, opts in (("fp32", "fp32", None), ("conv", "bf16", {"wg_gemm": 0}), ("gemm", "bf16", {"wg_gemm": 2}),
+                            ("gemm256", "bf16", {"wg_gemm": 3})):
         m = WaveGlow.remove_weightnorm(WaveGlow(**cfg))
         m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.waveglow_state(cfg, 3).items()})
         m.cuda().eval()
@@ -95,6 +96,9 @@ def test_waveglow_gate_gemm_agrees_with_the_conv_kernel():
         assert s_gemm >= 40.0 and abs(s_gemm - s_conv) <= 3.0, (b, s_conv, s_gemm)
         assert _snr(out["conv"][b, :n * 256], out["gemm"][b, :n * 256]) >= 45.0, b
         assert not out["gemm"][b, n * 256:].any()
+        # the residual conv on 256-row blocks: other tiles, the same contraction order per element
+        assert _snr(ref, out["gemm256"][b, :n * 256]) >= 40.0 and not out["gemm256"][b, n * 256:].any()
+        assert _snr(out["gemm"][b, :n * 256], out["gemm256"][b, :n * 256]) >= 45.0, b
 
 
 def test_waveglow_gate_gemm_is_deterministic_at_bench_size():
