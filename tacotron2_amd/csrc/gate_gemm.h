@@ -8,12 +8,13 @@
 // GEMM view: D[m][n] = sum_k W[m][k] X[n][k];  N = time steps of one sequence (tiles of 256); for the gated conv M = 2C
 // rows in (tanh, sigmoid) 16-row tile pairs (blocks of 256) and K = ktaps x C channels of the residual stream H (tap j
 // reads row n + (j - (ktaps-1)/2) dil, zero outside [0, len)) followed by the n_mel x n_group channels of the upsampled
-// mel; for the residual conv M = C (blocks of 128) and K = C gated channels.  Both operands are bfloat16 in memory (the
+// mel; for the residual conv M = C (blocks of 128, or of 256 in res_gemm256_kernel) and K = C gated channels.  Both operands are bfloat16 in memory (the
 // weights [M][K] row-major, activations channels-last), so a K tile of either one is rows of 128 contiguous bytes and
 // travels global -> LDS by `global_load_lds_dwordx4` without touching a register.
 //
 // Block: 8 waves as 2 (M) x 4 (N); a wave owns (16 MTW) x 64 of the tile = MTW x 4 accumulator tiles of
-// v_mfma_f32_16x16x32_bf16 (MTW = 8: 128 registers; MTW = 4: 64).
+// v_mfma_f32_16x16x32_bf16 (MTW = 8: 128 registers; MTW = 4: 64).  Results leave through an LDS tile in 16-byte units,
+// by non-temporal stores (no launch reads its own output).
 // LDS image: the 16-byte chunk c of row r sits at chunk position c ^ ((r >> 1) & 7) of the row.  The DMA writes
 // lane-linear (base + 16 lane), so the permutation is applied to each lane's SOURCE address; the fragment reads apply
 // the same XOR.  With it the four 16-lane groups of a ds_read_b128 (MI355X LDS: {0-3,12-15,20-27}, ...) each touch
