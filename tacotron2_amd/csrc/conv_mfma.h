@@ -388,7 +388,10 @@ struct WStream {
     }
     // fragments of K step `step` (clamped to the last one: prefetches past the end re-read it, harmlessly)
     __device__ __forceinline__ void fetch(u32x4 (&a)[TM + MV_XA], int step) const {
-        const int sn = step < S ? step : S - 1;
+        int sn = step < S ? step : S - 1;
+#if defined(MV_ABLATE) && (MV_ABLATE & 256)
+        sn &= 1;  // timing-only build: the weight stream re-reads two fragments (L1-resident): no L2 traffic
+#endif
 #if MV_XA
         a[TM] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, sn * 1024, 0);
 #endif
@@ -396,6 +399,12 @@ struct WStream {
         for (int tm = 0; tm < TM; ++tm) {
 #if defined(MV_ABLATE) && (MV_ABLATE & 4)
             a[tm] = u32x4{(unsigned)sn, 0u, 0u, 0u};  // timing-only build: no weight loads
+#elif defined(MV_ABLATE) && (MV_ABLATE & 1024)
+            // timing-only build: the weight fragments come out of LDS (whatever sits at its start) instead of L2
+            a[tm] = *(const u32x4*)((const __attribute__((address_space(3))) char*)0 + lane_off + ((tm + 2 * sn) & 7) * 1024);
+#elif defined(MV_ABLATE) && (MV_ABLATE & 512)
+            // timing-only build: one weight load per K step instead of TM
+            a[tm] = tm == 0 ? __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, sn * 1024, 0) : a[0];
 #else
             a[tm] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, tm * mtile_bytes + sn * 1024, 0);
 #endif
