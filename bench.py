@@ -27,10 +27,13 @@ The JSON line carries, besides the contract's fields,
                 results (<= 1e-3, the fp32 bar) from split bf16 operands, priced against bf16 peak / 3
   waveglow      BASELINE configs[2]: WaveGlow 12 flows x 8 layers x 512 ch, 80x500 mels, sigma 0.666, noise from
                 torch.manual_seed(1234); records B1 and B8 (bf16 operands) and B1_fp32
-  pcie          configs[3] on this one GPU with host buffers on both sides (host mels -> PCM16 on the host)
+  f16           the headline batch through MV_PREC_F16 (float16 operands, the bf16 kernels); snr_db_vs_fp32_mode = worst
+                per-utterance SNR of bf16 / f16 on the batch against the library's fp32 mode
+  sharded       configs[3] on the ranks of this run (every N, N = 1 included): 10 000 utterances bucketed, dealt to the
+                ranks longest-processing-time-first, host mels -> PCM16 on the host; value = audio seconds / slowest rank
   e2e           configs[4] on this one GPU: batched Tacotron2-shaped decode (PyTorch-ROCm) -> native Postnet -> native
                 vocoder, Tc2 and vocoder seconds separately
-(the last five at N = 1 only; --no-extras skips fp32 / waveglow / pcie / e2e).
+(all but `sharded` at N = 1 only; --no-extras skips them all).
 """
 import argparse
 import json
@@ -48,7 +51,7 @@ sys.path.insert(0, ROOT)
 SR = 22050.0
 # dense MFMA peaks, MI355X_MICROARCH.md.  bf16x3 (fp32-grade results from split bf16 operands, melvoc.h) executes three
 # bf16 MFMAs per algorithmic multiply-accumulate: its ceiling for ALGORITHMIC flops is a third of the bf16 peak.
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3}
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3}
 
 
 def parse(argv=None):
@@ -56,12 +59,13 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "bf16x3"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "fp32", "bf16x3"])
     ap.add_argument("--model", default="hifigan", choices=["hifigan", "waveglow", "postnet"])
     ap.add_argument("--batch", type=int, default=None, help="utterances per step (default 32; waveglow 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the fp32 / waveglow / pcie records")
+    ap.add_argument("--no-extras", action="store_true", help="skip the fp32 / f16 / waveglow / sharded / e2e records")
+    ap.add_argument("--no-sharded", action="store_true", help="skip the sharded-corpus record (configs[3])")
     ap.add_argument("--rows", action="store_true", help="per-kernel table on stderr")
     ap.add_argument("--options", default=None,
                     help='mv_options of the benched model as JSON, e.g. \'{"wg_gemm": 0}\' (A/B of kernel structures)')
@@ -72,11 +76,44 @@ def parse(argv=None):
 
 # ---------------------------------------------------------------------------------------------------------
 # launcher: `python bench.py --gpus N` without torch.distributed.run
-def launch_ranks(args, argv):
-    if not args.dry_run:
-        import torch
+def count_gpus_without_hip():
+    """GPU nodes of this machine WITHOUT touching HIP in this process (the launcher must not have initialised the GPU when
+    it starts its children): the KFD topology in sysfs lists every node with its SIMD count (CPUs have none) -- narrowed
+    by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when they are set; if sysfs is not readable, a throw-away child process
+    asks torch."""
+    import glob
 
-        have = torch.cuda.device_count()  # counts devices without initialising HIP in this (launcher) process
+    n = 0
+    found = False
+    for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            with open(path) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+        except OSError:
+            continue
+        found = True
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    if not found:
+        try:
+            out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                                 capture_output=True, text=True, timeout=300).stdout.strip().splitlines()
+            n = int(out[-1]) if out else 0
+        except (OSError, ValueError, subprocess.TimeoutExpired):
+            n = 0
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([t for t in v.split(",") if t.strip() != ""]))
+    return n
+
+
+def launch_ranks(args, argv, deadline_s=1500.0):
+    """Start one rank process per GPU, relay rank 0's line.  Every child is polled: the first one that exits non-zero
+    ends the run (the others are killed, by PID) instead of leaving rank 0 to sit in the rendezvous until its
+    store times out; an overall deadline bounds the whole launch."""
+    if not args.dry_run:
+        have = count_gpus_without_hip()
         if have < args.gpus:
             print(f"bench.py: --gpus {args.gpus} but this node shows {have} device(s)", file=sys.stderr)
             return 2
@@ -85,25 +122,40 @@ def launch_ranks(args, argv):
         port = s.getsockname()[1]
     procs = []
     for r in range(args.gpus):
+        # (the environment is inherited as is: HSA_ENABLE_IPC_MODE_LEGACY and friends are the box's business)
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode]
-    deadline = time.time() + 120
-    for p in procs[1:]:
-        try:
-            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
-        except subprocess.TimeoutExpired:
-            p.kill()  # this exact child
-            rcs.append(-9)
-    sys.stdout.write(out0 or "")
+    # rank 0's stdout is drained by a thread so that polling never blocks on a full pipe
+    import threading
+
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    t_end = time.time() + deadline_s
+    rcs = [None] * len(procs)
+    failed = None
+    while any(rc is None for rc in rcs):
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+                if rcs[r] not in (None, 0) and failed is None:
+                    failed = f"rank {r} exited with {rcs[r]}"
+        if failed is None and time.time() > t_end:
+            failed = f"deadline of {deadline_s:.0f} s passed"
+        if failed is not None:
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    p.kill()  # this exact child
+                    rcs[r] = p.wait()
+            break
+        time.sleep(0.05)
+    reader.join(10)
+    sys.stdout.write("".join(x or "" for x in out0))
     sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        print(f"bench.py: ranks failed: {bad}", file=sys.stderr)
+    if failed is not None or any(rc != 0 for rc in rcs):
+        print(f"bench.py: {failed or 'ranks failed'}; exit codes {rcs}", file=sys.stderr)
         return 1
     return 0
 
@@ -212,6 +264,24 @@ def build_model(torch, model, dtype, batch, rank, dev, options=None):
     return m, run, float(lengths.sum()), workload, B
 
 
+def waveglow_reference_macs_per_frame(cfg):
+    """Multiply-accumulates per mel frame of WaveGlow.infer in the REFERENCE's formulation (SURVEY.md section 8a rows
+    W1-W10: cond_layer, in_layers, res_skip with its skip halves, end, 1x1 convs, upsampler) -- 1.4407 TFLOP per audio
+    second at 512 channels.  The library's bf16 mode executes less (folded skip path); mv_macs_per_frame reports that."""
+    wn = cfg["WN_config"]
+    C, nl, ks = wn["n_channels"], wn["n_layers"], wn["kernel_size"]
+    ng, nm = cfg["n_group"], cfg["n_mel_channels"]
+    ncond = nm * ng
+    per_step, n_half, n_rem = 0.0, ng // 2, ng
+    for k in range(cfg["n_flows"]):
+        if k % cfg["n_early_every"] == 0 and k > 0:
+            n_half -= cfg["n_early_size"] // 2
+            n_rem -= cfg["n_early_size"]
+        per_step += (n_half * C + ncond * 2 * C * nl + nl * 2 * C * C * ks + (nl - 1) * 2 * C * C + C * C + C * 2 * n_half
+                     + n_rem * n_rem)
+    return per_step * (256 // ng) + nm * nm * 1024
+
+
 def roofline_of(torch, m, run, frames, dev, model, dtype, batch, nprof, show_rows):
     h = m.native_handle(dev)
     h.profile_begin()
@@ -272,22 +342,36 @@ def side_record(torch, model, dtype, batch, dev, steps, warmup, show_rows):
            "gflop_per_audio_s": round(2.0 * macs * SR / 256 / 1e9, 3),
            "frac_of_mfma_roofline": round(audio_s * steps / dt / peak_audio, 4),
            "roofline": roofline_of(torch, m, run, frames, dev, model, dtype, B, max(1, min(steps, 3)), show_rows)}
+    if model == "waveglow":
+        # the same throughput priced with the REFERENCE's formulation (1.4407 TFLOP per audio second),
+        # beside the executed count above (bf16 mode folds the skip path and executes less)
+        from tacotron2_amd import synth
+
+        ref_macs = waveglow_reference_macs_per_frame(synth.WAVEGLOW_512)
+        rec["gflop_per_audio_s_reference"] = round(2.0 * ref_macs * SR / 256 / 1e9, 3)
+        rec["frac_of_mfma_roofline_reference_flops"] = round(
+            audio_s * steps / dt * (2.0 * ref_macs * SR / 256) / (PEAK_TFLOPS[dtype] * 1e12), 4)
     del m, run
     torch.cuda.empty_cache()
     return rec
 
 
-def pcie_record(torch, dev):
-    """BASELINE configs[3] on this one GPU: host mels -> pinned -> H2D -> vocode -> PCM16 -> D2H -> host arrays, the
-    pipeline of tacotron2_amd.batch.synthesize_shard (never `value`: it includes PCIe and host work)."""
+def sharded_record(torch, dist, dev, rank, world, dtype):
+    """BASELINE configs[3] -- what north_star's scaling target is about -- on the ranks of this run: 10 000 synthetic
+    utterances of 2-10 s, length-bucketed (<= 32 per call, <= 64 frames apart), buckets dealt to the ranks
+    longest-processing-time-first on their frame totals (no data-path collective), and on every rank the whole host
+    path: float32 mels in host memory -> pinned -> H2D -> vocode -> PCM16 -> D2H -> a per-utterance sink that is handed a
+    view of the pinned slot (tacotron2_amd.batch.synthesize_shard).  value = sum of audio seconds / the slowest rank's
+    wall time; never the headline `value` (it includes PCIe and host work).  Called by EVERY rank; rank 0 gets the record."""
     from tacotron2_amd import batch as vb
     from tacotron2_amd import do_syn_batch, synth
 
-    n = 2000
-    voc = do_syn_batch.build_vocoder("synthetic-hifigan", dev, "bf16")
+    n = 10000
+    voc = do_syn_batch.build_vocoder("synthetic-hifigan", dev, dtype)
     lens = synth.synthetic_lengths(n, 1234)
     base = [synth.synthetic_mel(int(lens.max()), 7 + i) for i in range(16)]  # 16 distinct mels, cut to length: the host-side
     mels = [base[i % 16][:, : int(T)] for i, T in enumerate(lens)]  # generator is not what is being timed
+    lengths = [int(t) for t in lens]
     seen = [0]
 
     def sink(i, pcm):  # what a WAV writer would be handed: a view of the pinned download slot
@@ -295,14 +379,51 @@ def pcie_record(torch, dev):
 
     vb.synthesize_shard(voc, mels[:64], device=dev, sink=sink)  # warm-up (workspace growth, pinned slots)
     seen[0] = 0
-    _, st = vb.synthesize_shard(voc, mels, device=dev, sink=sink)
-    audio_s = float(lens.sum()) * 256 / SR
-    assert seen[0] == int(lens.sum()) * 256
-    return {"value": round(audio_s / st.wall_seconds, 2), "unit": "audio-s/s", "utterances": n,
-            "wall_s": round(st.wall_seconds, 3), "calls": st.calls, "checksum": st.checksum,
-            "workload": "do_syn-style batch on one GPU (BASELINE configs[3] shape): 2000 synthetic utterances of "
-                        "2-10 s, host float32 mels -> int16 PCM in pinned host memory handed to a per-utterance "
-                        "sink, length-bucketed (<= 32 per call), pad / H2D / vocode / D2H overlapped"}
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    _, st = vb.synthesize_shard(voc, mels, lengths, rank=rank, world=world, device=dev, sink=sink)
+    assert seen[0] == st.frames * 256
+    total = vb.gather_stats(st, device=dev)
+    per = sorted(total.per_rank, key=lambda p: p.rank)
+    frames = [p.frames for p in per]
+    mean = sum(frames) / len(frames)
+    return {"value": round(total.audio_seconds / total.wall_seconds, 2), "unit": "audio-s/s", "n_gpus": world,
+            "utterances": total.utterances, "calls": total.calls, "audio_seconds": round(total.audio_seconds, 1),
+            "wall_s": round(total.wall_seconds, 3), "per_rank_wall_s": [round(p.wall_seconds, 3) for p in per],
+            "per_rank_audio_s": [round(p.audio_seconds, 1) for p in per],
+            "lpt_load_spread": round((max(frames) - min(frames)) / mean, 5) if mean else 0.0,
+            "checksum": total.checksum, "dtype": dtype, "scaling": "strong",
+            "workload": "do_syn-style batch (BASELINE configs[3]): 10000 synthetic utterances of 2-10 s (lengths "
+                        "synth.synthetic_lengths(10000, 1234)), host float32 mels -> int16 PCM in pinned host memory handed "
+                        "to a per-utterance sink, length-bucketed (<= 32 per call), buckets dealt to the ranks "
+                        "longest-processing-time-first, pad / H2D / vocode / D2H overlapped on every rank; value = total "
+                        "audio seconds / slowest rank's wall"}
+
+
+def snr_record(torch, dev):
+    """Worst per-utterance SNR of the 16-bit-operand modes on the bench batch against the library's fp32 mode (which the
+    goldens pin to the reference at <= 1e-3): BASELINE's bar is >= 40 dB."""
+    out = {}
+    ref = None
+    for dtype in ("fp32", "bf16", "f16"):
+        m, run, _, _, _ = build_model(torch, "hifigan", dtype, None, 0, dev)
+        y = run()[:, 0].double()
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = y
+            lengths = np.sort(__import__("tacotron2_amd.synth", fromlist=["x"]).synthetic_lengths(32, 1234))[::-1]
+            continue
+        worst = 1e9
+        for b, T in enumerate(lengths):
+            n = int(T) * 256
+            num = float((ref[b, :n] ** 2).sum())
+            den = max(float(((ref[b, :n] - y[b, :n]) ** 2).sum()), 1e-300)
+            worst = min(worst, 10.0 * np.log10(num / den))
+        out[dtype] = round(float(worst), 2)
+        del m, run
+    torch.cuda.empty_cache()
+    return out
 
 
 def e2e_record(torch, dev):
@@ -384,6 +505,16 @@ def run_rank(args):
         total_audio = audio_s
     value = total_audio * args.steps / dt
 
+    # BASELINE configs[3] on the ranks of THIS run (every rank takes part; N = 1 included)
+    sharded = None
+    if args.model == "hifigan" and not args.no_extras and not args.no_sharded and args.batch in (None, 32):
+        try:
+            sharded = sharded_record(torch, dist, dev, rank, world, args.dtype)
+        except Exception as e:  # secondary: never lose the headline to it
+            if world > 1:
+                raise  # (a rank that left the collective would hang the others: fail loudly instead)
+            sharded = {"error": repr(e)[:200]}
+
     if rank == 0:
         roofline = None
         if not args.no_profile:
@@ -419,17 +550,22 @@ def run_rank(args):
             torch.cuda.empty_cache()
             line["fp32"] = side_record(torch, "hifigan", "fp32", None, dev, 10, 2, args.rows)
             line["fp32"]["bf16x3"] = side_record(torch, "hifigan", "bf16x3", None, dev, 20, 3, args.rows)
+            # float16 operands (MV_PREC_F16): the bf16 kernels and rate with 11 significant bits per operand
+            line["f16"] = side_record(torch, "hifigan", "f16", None, dev, 50, 5, args.rows)
+            line["f16"]["vs_bf16_throughput"] = round(line["f16"]["value"] / value, 4)
+            line["snr_db_vs_fp32_mode"] = snr_record(torch, dev)
             line["waveglow"] = {
                 "B1": side_record(torch, "waveglow", "bf16", 1, dev, 60, 5, args.rows),
                 "B8": side_record(torch, "waveglow", "bf16", 8, dev, 10, 2, args.rows),
                 "B1_fp32": side_record(torch, "waveglow", "fp32", 1, dev, 5, 1, args.rows),
                 "B1_bf16x3": side_record(torch, "waveglow", "bf16x3", 1, dev, 10, 2, args.rows),
             }
-            for key, fn in (("pcie", pcie_record), ("e2e", e2e_record)):
-                try:
-                    line[key] = fn(torch, dev)
-                except Exception as e:  # secondary: never lose the headline to it
-                    line[key] = {"error": repr(e)[:200]}
+            try:
+                line["e2e"] = e2e_record(torch, dev)
+            except Exception as e:  # secondary: never lose the headline to it
+                line["e2e"] = {"error": repr(e)[:200]}
+        if sharded is not None:
+            line["sharded"] = sharded
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(torch)
         print(json.dumps(line), flush=True)

@@ -52,6 +52,12 @@ extern "C" {
                             between kernels stay float32, the order of operations is MV_PREC_FP32's.  Meets the fp32 bar
                             (max-abs <= 1e-3; ~5e-5 measured) at a third of the bf16 MFMA rate instead of a sixteenth. */
 
+#define MV_PREC_F16 3 /* float16 operands (v_mfma_f32_16x16x32_f16: the bf16 instruction's cycles), fp32 accumulate, fp32
+                         residual stream, float16 activations between kernels: MV_PREC_BF16's kernels and speed with 11
+                         significant bits per operand instead of 8 (HiFi-GAN: ~18 dB more SNR than bf16).  Every
+                         conversion to an operand saturates at +-65504.  WaveGlow runs its layer-by-layer structure in
+                         this mode (no ring GEMMs, no folded skip path). */
+
 /* output sample formats of mv_hifigan_forward / mv_waveglow_infer */
 #define MV_OUT_F32 0   /* float32 in (-1,1), what Generator.forward / WaveGlow.infer return */
 #define MV_OUT_PCM16 1 /* int16 = (int16)(int32)(32768.0f * y): do_syn.py:11,389-394 (truncate, no clip) */

@@ -14,10 +14,11 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MELVOC_LIB") or os.path.join(_HERE, "libmelvoc.so")  # MELVOC_LIB: diagnostic builds
 
-PREC_FP32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
+PREC_FP32, PREC_BF16, PREC_BF16X3, PREC_F16 = 0, 1, 2, 3
 OUT_F32, OUT_PCM16 = 0, 1
 PRECISIONS = {"fp32": PREC_FP32, "float32": PREC_FP32, "bf16": PREC_BF16, "bfloat16": PREC_BF16,
-              "bf16x3": PREC_BF16X3}  # bf16x3: fp32-grade results from split bf16 operands (melvoc.h)
+              "bf16x3": PREC_BF16X3,  # bf16x3: fp32-grade results from split bf16 operands (melvoc.h)
+              "f16": PREC_F16, "fp16": PREC_F16, "float16": PREC_F16}  # float16 operands at the bf16 rate (melvoc.h)
 
 EXPORTS = (
     "mv_backend", "mv_last_error", "mv_hifigan_create", "mv_hifigan_forward", "mv_waveglow_create",

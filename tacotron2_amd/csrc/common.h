@@ -54,6 +54,7 @@ struct Layer {
     int cfg = 0;  // index into kTileCfgs
     bool bf16 = false;  // bf16 MFMA operands ...
     bool x3 = false;    // ... each float32 value as a (hi, lo) pair of them (MV_PREC_BF16X3, conv_mfma.h split_bf16x2)
+    int opf = OP_BF16;  // format of the 16-bit operands: OP_BF16, or OP_F16 (MV_PREC_F16)
     int epi = EPI_LINEAR;
     size_t lds_bytes = 0;
     double macs_per_n = 0;  // padded MACs per output row (diagnostics)
@@ -87,7 +88,7 @@ struct SrcSpec {
     std::function<float(int, int, int)> w;
 };
 
-// `prec` is MV_PREC_* (0 fp32, 1 bf16, 2 bf16x3) here and in the builders below
+// `prec` is MV_PREC_* (0 fp32, 1 bf16, 2 bf16x3, 3 f16) here and in the builders below
 // one_pass: pack every source as a single [tap][k-chunk] pass whatever its LDS footprint (weights for the fused
 // kernels of fused_rb.h, which keep their own tiles; such a layer is never launched through launch_layer)
 int build_layer(Layer* L, const std::vector<SrcSpec>& srcs, int M, const std::vector<float>& bias, int prec, int epi,

@@ -35,6 +35,10 @@ constexpr int kMfmaPrio = 3;    // s_setprio while a wave issues an MFMA group: 
 constexpr int kLdsRowPad = 32;  // bytes; row stride/16 == 2 (mod 4) makes ds_read_b128 conflict-free
 
 enum { EPI_LINEAR = 0, EPI_GATE = 1 };
+// 16-bit MFMA operand formats (template parameter OPF of the "BF16" kernels): bfloat16 (MV_PREC_BF16, MV_PREC_BF16X3) or
+// float16 (MV_PREC_F16: v_mfma_f32_16x16x32_f16 takes the same cycles; 11 significant bits instead of 8, range +-65504,
+// so every conversion to it saturates)
+enum { OP_BF16 = 0, OP_F16 = 1 };
 enum { ACC_STORE = 0, ACC_ADD = 1, ACC_ADD_DIV = 2 };
 
 struct ConvPass {
@@ -85,14 +89,17 @@ struct ConvParams {
     int nx;              // row tiles (xcd_ny > 0)
 };
 
-template <bool BF16>
+template <bool BF16, int OPF = OP_BF16>
 __device__ __forceinline__ void mma16(f32x4& acc, const u32x4& a, const u32x4& b) {
 #if defined(MV_ABLATE) && (MV_ABLATE & 1)
     // timing-only build (tools/ablate.sh; MV_ABLATE is a bit mask): keep the operands live, issue no MFMA
     asm volatile("" ::"v"(a), "v"(b));
     return;
 #endif
-    if constexpr (BF16) {
+    if constexpr (BF16 && OPF == OP_F16) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0,
+                                                     0, 0);
+    } else if constexpr (BF16) {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
                                                       acc, 0, 0, 0);
     } else {
@@ -153,10 +160,13 @@ __device__ __forceinline__ f32x4 ld4(const void* base, long long e, int f16) {
     return *(const f32x4*)((const float*)base + e);
 }
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi);
+template <int OPF>
+__device__ __forceinline__ unsigned pack_op(float lo, float hi);
+template <int OPF = OP_BF16>
 __device__ __forceinline__ void st4(void* base, long long e, const f32x4& v, int f16) {
-    if (f16 == 2) {  // bfloat16 (operand-only tensors, see ConvPass::src_f16)
+    if (f16 == 2) {  // MFMA-operand format (operand-only tensors, see ConvPass::src_f16)
         *(unsigned long long*)((unsigned short*)base + e) =
-            ((unsigned long long)pack_bf16(v[2], v[3]) << 32) | pack_bf16(v[0], v[1]);
+            ((unsigned long long)pack_op<OPF>(v[2], v[3]) << 32) | pack_op<OPF>(v[0], v[1]);
     } else if (f16) {
         f16x4 h;
 #pragma unroll
@@ -171,6 +181,19 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
     bf16x2 v = {(__bf16)lo, (__bf16)hi};
     return __builtin_bit_cast(unsigned, v);
+}
+// two values as MFMA operands of format OPF (round to nearest even; float16 saturates at +-65504: an operand that
+// became inf would turn every product with a zero into NaN)
+template <int OPF>
+__device__ __forceinline__ unsigned pack_op(float lo, float hi) {
+    if constexpr (OPF == OP_F16) {
+        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+        f16x2 v = {(_Float16)__builtin_amdgcn_fmed3f(lo, -65504.f, 65504.f),
+                   (_Float16)__builtin_amdgcn_fmed3f(hi, -65504.f, 65504.f)};
+        return __builtin_bit_cast(unsigned, v);
+    } else {
+        return pack_bf16(lo, hi);
+    }
 }
 
 // The same for a bfloat16 source (ConvPass::src_f16 == 2): the tile is a plain copy, 16 bytes = 8 channels per unit.
@@ -221,7 +244,7 @@ __device__ __forceinline__ void split_bf16x2(const f32x4& a, const f32x4& b, u32
     }
 }
 
-template <bool BF16, int NTHREADS, bool X3 = false>
+template <bool BF16, int NTHREADS, bool X3 = false, int OPF = OP_BF16>
 __device__ __forceinline__ void stage_tile(char* smem, const ConvPass& cp, const void* src_b, int row0, int rows,
                                            int len_rows, int RS) {
     constexpr int UC = BF16 ? 8 : 4;  // channels per 16-byte LDS unit
@@ -279,10 +302,10 @@ __device__ __forceinline__ void stage_tile(char* smem, const ConvPass& cp, const
                     split_bf16x2(y0, y1, v, lo);
                     *(u32x4*)(smem + dst[k] + cp.cb * 2) = lo;
                 } else {
-                    v[0] = pack_bf16(y0[0], y0[1]);
-                    v[1] = pack_bf16(y0[2], y0[3]);
-                    v[2] = pack_bf16(y1[0], y1[1]);
-                    v[3] = pack_bf16(y1[2], y1[3]);
+                    v[0] = pack_op<OPF>(y0[0], y0[1]);
+                    v[1] = pack_op<OPF>(y0[2], y0[3]);
+                    v[2] = pack_op<OPF>(y1[0], y1[1]);
+                    v[3] = pack_op<OPF>(y1[2], y1[3]);
                 }
             } else {
                 v = __builtin_bit_cast(u32x4, y0);
@@ -327,7 +350,7 @@ __device__ __forceinline__ void load_bgroup(u32x4 (&q)[G], const char* bp, int R
 #define MV_XA 0
 #endif
 
-template <bool BF16, int TM, int TN, int PAR>
+template <bool BF16, int TM, int TN, int PAR, int OPF = OP_BF16>
 __device__ __forceinline__ void mma_step(f32x4 (&acc)[TM][TN], const u32x4 (&a)[TM + MV_XA], const char* bp,
                                          const char* bp_next, int RS, u32x4 (&q0)[BPipe<TM, TN>::G],
                                          u32x4 (&q1)[BPipe<TM, TN>::G]) {
@@ -357,7 +380,7 @@ __device__ __forceinline__ void mma_step(f32x4 (&acc)[TM][TN], const u32x4 (&a)[
         for (int j = 0; j < G; ++j) {
             if (g * G + j < TN) {
 #pragma unroll
-                for (int tm = 0; tm < TM; ++tm) mma16<BF16>(acc[tm][g * G + j], a[tm], cur0 ? q0[j] : q1[j]);
+                for (int tm = 0; tm < TM; ++tm) mma16<BF16, OPF>(acc[tm][g * G + j], a[tm], cur0 ? q0[j] : q1[j]);
             }
         }
         __builtin_amdgcn_s_setprio(0);
@@ -432,7 +455,7 @@ struct APre {
 // X3 (split operands, see split_bf16x2): a tap walks 3*nkc K steps over a row's [hi | lo] halves -- the hi chunks
 // against w_hi, the lo chunks against w_hi, then the hi chunks again against w_lo (the host packs the weight
 // fragments in that order) -- so the B pointer steps back over both halves once per tap.
-template <bool BF16, int TM, int TN, int DEPTH = 4, bool X3 = false>
+template <bool BF16, int TM, int TN, int DEPTH = 4, bool X3 = false, int OPF = OP_BF16>
 __device__ __forceinline__ void mma_pass(f32x4 (&acc)[TM][TN], const char* lds_b, int RS, int ktaps, int dil, int nkc,
                                          const u32x4* wlane, long long mtile_stride,
                                          const APre<TM, DEPTH>* pre = nullptr) {
@@ -484,43 +507,44 @@ __device__ __forceinline__ void mma_pass(f32x4 (&acc)[TM][TN], const char* lds_b
     if constexpr (DEPTH == 2) {
         for (; s + 2 <= S; s += 2) {
             const char* bp1 = next_bp(bp);
-            mma_step<BF16, TM, TN, 0>(acc, a0, bp, bp1, RS, q0, q1);
+            mma_step<BF16, TM, TN, 0, OPF>(acc, a0, bp, bp1, RS, q0, q1);
             fetch(a0, s + 2);
             const char* bp2 = s + 2 < S ? next_bp(bp1) : bp1;
-            mma_step<BF16, TM, TN, P1>(acc, a1, bp1, bp2, RS, q0, q1);
+            mma_step<BF16, TM, TN, P1, OPF>(acc, a1, bp1, bp2, RS, q0, q1);
             fetch(a1, s + 3);
             bp = bp2;
         }
-        if (s < S) mma_step<BF16, TM, TN, 0>(acc, a0, bp, bp, RS, q0, q1);
+        if (s < S) mma_step<BF16, TM, TN, 0, OPF>(acc, a0, bp, bp, RS, q0, q1);
     } else {
     for (; s + 4 <= S; s += 4) {
         const char* bp1 = next_bp(bp);
-        mma_step<BF16, TM, TN, 0>(acc, a0, bp, bp1, RS, q0, q1);
+        mma_step<BF16, TM, TN, 0, OPF>(acc, a0, bp, bp1, RS, q0, q1);
         fetch(a0, s + 4);
         const char* bp2 = next_bp(bp1);
-        mma_step<BF16, TM, TN, P1>(acc, a1, bp1, bp2, RS, q0, q1);
+        mma_step<BF16, TM, TN, P1, OPF>(acc, a1, bp1, bp2, RS, q0, q1);
         fetch(a1, s + 5);
         const char* bp3 = next_bp(bp2);
-        mma_step<BF16, TM, TN, 0>(acc, a2, bp2, bp3, RS, q0, q1);
+        mma_step<BF16, TM, TN, 0, OPF>(acc, a2, bp2, bp3, RS, q0, q1);
         fetch(a2, s + 6);
         // past the last step there is nothing to read ahead: re-read this one (harmless)
         const char* bp4 = s + 4 < S ? next_bp(bp3) : bp3;
-        mma_step<BF16, TM, TN, P1>(acc, a3, bp3, bp4, RS, q0, q1);
+        mma_step<BF16, TM, TN, P1, OPF>(acc, a3, bp3, bp4, RS, q0, q1);
         fetch(a3, s + 7);
         bp = bp4;
     }
     if (s < S) {
         const char* bp1 = s + 1 < S ? next_bp(bp) : bp;
-        mma_step<BF16, TM, TN, 0>(acc, a0, bp, bp1, RS, q0, q1);
+        mma_step<BF16, TM, TN, 0, OPF>(acc, a0, bp, bp1, RS, q0, q1);
         if (s + 1 < S) {
             const char* bp2 = s + 2 < S ? next_bp(bp1) : bp1;
-            mma_step<BF16, TM, TN, P1>(acc, a1, bp1, bp2, RS, q0, q1);
-            if (s + 2 < S) mma_step<BF16, TM, TN, 0>(acc, a2, bp2, bp2, RS, q0, q1);
+            mma_step<BF16, TM, TN, P1, OPF>(acc, a1, bp1, bp2, RS, q0, q1);
+            if (s + 2 < S) mma_step<BF16, TM, TN, 0, OPF>(acc, a2, bp2, bp2, RS, q0, q1);
         }
     }
     }
 }
 
+template <int OPF = OP_BF16>
 __device__ __forceinline__ void store_out(const ConvOut& o, int b, long long e, long long valid, f32x4 v,
                                           const void* resid_b, float div) {
     if (e < 0 || e >= valid) return;
@@ -535,16 +559,17 @@ __device__ __forceinline__ void store_out(const ConvOut& o, int b, long long e, 
         v[2] = v[2] / div;
         v[3] = v[3] / div;
     }
-    st4(o.ptr, eb, v, o.f16);
-    if (o.copy_bf16) st4(o.copy_bf16, eb, v, 2);
+    st4<OPF>(o.ptr, eb, v, o.f16);
+    if (o.copy_bf16) st4<OPF>(o.copy_bf16, eb, v, 2);
 }
 
 // 4-wave tiles with 64 accumulator registers fit 3 waves per SIMD (<= 168 VGPRs; the allocator lands just above
 // that on its own): a third resident block per CU is what the HBM-bound low-channel layers need (bytes in flight).
-template <bool BF16, int TM, int TN, int WM, int WN, int EPI, bool X3 = false>
+template <bool BF16, int TM, int TN, int WM, int WN, int EPI, bool X3 = false, int OPF = OP_BF16>
 __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(TM * TN <= 16 && WM * WN == 4 ? 3 : 2)))
 void conv_cl_kernel(const ConvParams p) {
     static_assert(BF16 || !X3, "split operands are bf16 operands");
+    static_assert(OPF == OP_BF16 || (BF16 && !X3), "float16 operands: the 16-bit path, unsplit");
     constexpr int MT = 16 * TM * WM, NT = 16 * TN * WN, NTHREADS = WM * WN * 64;
     constexpr int ES = BF16 && !X3 ? 2 : 4;  // bytes of LDS per staged element (X3: a bf16 pair)
     constexpr int CH = BF16 ? 32 : 16;
@@ -593,12 +618,12 @@ void conv_cl_kernel(const ConvParams p) {
         if (BF16 && !X3 && cp.src_f16 == 2)
             stage_tile_raw<NTHREADS>(smem, cp, src_b, n0 - cp.pad_left, rows, len * cp.rows_per_frame, RS);
         else
-            stage_tile<BF16, NTHREADS, X3>(smem, cp, src_b, n0 - cp.pad_left, rows, len * cp.rows_per_frame, RS);
+            stage_tile<BF16, NTHREADS, X3, OPF>(smem, cp, src_b, n0 - cp.pad_left, rows, len * cp.rows_per_frame, RS);
         __syncthreads();
         const int nkc = cp.cb / CH;
         const char* lds_b = smem + (wn * TN * 16 + lr) * RS + lg * 16;
-        mma_pass<BF16, TM, TN, 4, X3>(acc, lds_b, RS, cp.ktaps, cp.dil, nkc, wlane + (long long)step_base * 64,
-                                      mtile_stride);
+        mma_pass<BF16, TM, TN, 4, X3, OPF>(acc, lds_b, RS, cp.ktaps, cp.dil, nkc, wlane + (long long)step_base * 64,
+                                           mtile_stride);
         step_base += cp.ktaps * nkc * (X3 ? 3 : 1);
     }
 
@@ -628,9 +653,9 @@ void conv_cl_kernel(const ConvParams p) {
                         const int nl = (wn * TN + tn) * 16 + lr;
                         f32x4 v = acc[tm][tn] + bias;
                         if (p.act == 1) v = f32x4{tanhf(v[0]), tanhf(v[1]), tanhf(v[2]), tanhf(v[3])};
-                        if (p.out[0].f16 == 2) {  // bfloat16 output (operand-only tensor): the tile holds bf16
+                        if (p.out[0].f16 == 2) {  // operand-format output (operand-only tensor): the tile holds it as such
                             *(unsigned long long*)(smem + nl * TRS + ml * 2) =
-                                ((unsigned long long)pack_bf16(v[2], v[3]) << 32) | pack_bf16(v[0], v[1]);
+                                ((unsigned long long)pack_op<OPF>(v[2], v[3]) << 32) | pack_op<OPF>(v[0], v[1]);
                         } else {
                             f16x4 h;
 #pragma unroll
@@ -656,7 +681,7 @@ void conv_cl_kernel(const ConvParams p) {
                         for (int j = 0; j < 4; ++j) gv[j] = gate_act<BF16>(t[j], sg[j]);
                         if (p.out[0].f16 == 2) {
                             *(unsigned long long*)(smem + nl * TRS + cl * 2) =
-                                ((unsigned long long)pack_bf16(gv[2], gv[3]) << 32) | pack_bf16(gv[0], gv[1]);
+                                ((unsigned long long)pack_op<OPF>(gv[2], gv[3]) << 32) | pack_op<OPF>(gv[0], gv[1]);
                         } else {
                             f16x4 h;
 #pragma unroll
@@ -732,8 +757,8 @@ void conv_cl_kernel(const ConvParams p) {
                     }
                     if (o.copy_bf16)
                         *(u32x4*)((unsigned short*)o.copy_bf16 + eb) =
-                            u32x4{pack_bf16(y[0][0], y[0][1]), pack_bf16(y[0][2], y[0][3]), pack_bf16(y[1][0], y[1][1]),
-                                  pack_bf16(y[1][2], y[1][3])};
+                            u32x4{pack_op<OPF>(y[0][0], y[0][1]), pack_op<OPF>(y[0][2], y[0][3]),
+                                  pack_op<OPF>(y[1][0], y[1][1]), pack_op<OPF>(y[1][2], y[1][3])};
                 }
             }
             return;
@@ -755,7 +780,7 @@ void conv_cl_kernel(const ConvParams p) {
                 const long long e = (long long)n * o.row_stride + m + o.off;
                 f32x4 v = acc[tm][tn] + bias;
                 if (p.act == 1) v = f32x4{tanhf(v[0]), tanhf(v[1]), tanhf(v[2]), tanhf(v[3])};
-                store_out(o, b, e, valid, v, oi ? nullptr : resid_b, p.div);
+                store_out<OPF>(o, b, e, valid, v, oi ? nullptr : resid_b, p.div);
             }
         }
     } else {
@@ -779,7 +804,7 @@ void conv_cl_kernel(const ConvParams p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) g[j] = gate_act<BF16>(t[j], s[j]);
                 const long long e = (long long)n * o.row_stride + ch + o.off;
-                store_out(o, b, e, valid, g, nullptr, 1.f);
+                store_out<OPF>(o, b, e, valid, g, nullptr, 1.f);
             }
         }
     }

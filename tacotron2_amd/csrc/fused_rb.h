@@ -101,11 +101,11 @@ struct FusedRbParams {
 };
 
 // acc += conv over the window (the caller initialises acc)
-template <int TM, int TN, int DEPTH = 4, bool X3 = false>
+template <int TM, int TN, int DEPTH = 4, bool X3 = false, int OPF = OP_BF16>
 __device__ __forceinline__ void conv_window(f32x4 (&acc)[TM][TN], const char* lds_b, int RS, int ktaps, int dil,
                                             int nkc, const u32x4* wlane, long long mtile_stride,
                                             const APre<TM, DEPTH>* pre = nullptr) {
-    mma_pass<true, TM, TN, DEPTH, X3>(acc, lds_b, RS, ktaps, dil, nkc, wlane, mtile_stride, pre);
+    mma_pass<true, TM, TN, DEPTH, X3, OPF>(acc, lds_b, RS, ktaps, dil, nkc, wlane, mtile_stride, pre);
 }
 
 // Biases of every conv of a launch live in LDS behind the two tiles ([conv][C] floats, filled once per persistent
@@ -123,21 +123,55 @@ __device__ __forceinline__ f32x4 lrelu4(const f32x4& v, float slope) {
     return f32x4{fmaxf(v[0], s[0]), fmaxf(v[1], s[1]), fmaxf(v[2], s[2]), fmaxf(v[3], s[3])};
 }
 
+// (the pack*_bf16 helpers below produce MFMA operands of format OPF: bfloat16, or saturating float16)
+template <int OPF = OP_BF16>
 __device__ __forceinline__ unsigned long long pack4_bf16(const f32x4& v) {
-    return ((unsigned long long)pack_bf16(v[2], v[3]) << 32) | pack_bf16(v[0], v[1]);
+    return ((unsigned long long)pack_op<OPF>(v[2], v[3]) << 32) | pack_op<OPF>(v[0], v[1]);
 }
 
+template <int OPF = OP_BF16>
 __device__ __forceinline__ unsigned long long pack4_bf16_lrelu(const f32x4& v, float slope, bool keep) {
-    return keep ? pack4_bf16(lrelu4(v, slope)) : 0ull;
+    return keep ? pack4_bf16<OPF>(lrelu4(v, slope)) : 0ull;
 }
 
 // 8 consecutive channels of one row = the lane's fragments of its two M tiles (pair-interleaved channel order,
 // see fused_rb_kernel): one 16-byte LDS unit
+template <int OPF = OP_BF16>
 __device__ __forceinline__ u32x4 pack8_bf16(const f32x4& a, const f32x4& b) {
-    return u32x4{pack_bf16(a[0], a[1]), pack_bf16(a[2], a[3]), pack_bf16(b[0], b[1]), pack_bf16(b[2], b[3])};
+    return u32x4{pack_op<OPF>(a[0], a[1]), pack_op<OPF>(a[2], a[3]), pack_op<OPF>(b[0], b[1]), pack_op<OPF>(b[2], b[3])};
 }
+// leaky_relu + conversion to operands in one go.  float16 operands must not overflow to inf (inf * 0 = NaN in the
+// next MFMA); the clamp is folded into the activation instead of costing two more instructions per value:
+//   upper side: max(x, s x) clamped at 65504 is the MEDIAN of (x, s x, 65504) for 0 < s < 1 -- one v_med3 in place
+//               of the v_max;
+//   lower side: one packed v_pk_max_f16 with -65504 on the converted pair (-inf -> -65504);
+// INRANGE: the values are float16 values already (a window as it arrived from memory): no clamp at all.
+template <int OPF, bool INRANGE>
+__device__ __forceinline__ unsigned lrelu_pack2(float x0, float x1, float s0, float s1) {
+    if constexpr (OPF == OP_F16) {
+        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+        if constexpr (INRANGE) {
+            const f16x2 v = {(_Float16)fmaxf(x0, s0), (_Float16)fmaxf(x1, s1)};
+            return __builtin_bit_cast(unsigned, v);
+        } else {
+            f16x2 v = {(_Float16)__builtin_amdgcn_fmed3f(x0, s0, 65504.f), (_Float16)__builtin_amdgcn_fmed3f(x1, s1, 65504.f)};
+            const f16x2 lo = {(_Float16)-65504.f, (_Float16)-65504.f};
+            v = __builtin_elementwise_max(v, lo);
+            return __builtin_bit_cast(unsigned, v);
+        }
+    } else {
+        return pack_bf16(fmaxf(x0, s0), fmaxf(x1, s1));
+    }
+}
+template <int OPF = OP_BF16, bool INRANGE = false>
+__device__ __forceinline__ u32x4 pack8_lrelu(const f32x4& a, const f32x4& b, float slope) {
+    const f32x4 sa = a * slope, sb = b * slope;
+    return u32x4{lrelu_pack2<OPF, INRANGE>(a[0], a[1], sa[0], sa[1]), lrelu_pack2<OPF, INRANGE>(a[2], a[3], sa[2], sa[3]),
+                 lrelu_pack2<OPF, INRANGE>(b[0], b[1], sb[0], sb[1]), lrelu_pack2<OPF, INRANGE>(b[2], b[3], sb[2], sb[3])};
+}
+template <int OPF = OP_BF16, bool INRANGE = false>
 __device__ __forceinline__ u32x4 pack8_bf16_lrelu(const f32x4& a, const f32x4& b, float slope, bool keep) {
-    return keep ? pack8_bf16(lrelu4(a, slope), lrelu4(b, slope)) : u32x4{0u, 0u, 0u, 0u};
+    return keep ? pack8_lrelu<OPF, INRANGE>(a, b, slope) : u32x4{0u, 0u, 0u, 0u};
 }
 __device__ __forceinline__ u32x4 pack8_f16_sat(const f32x4& a, const f32x4& b) {
     f16x8 h;
@@ -273,7 +307,7 @@ __device__ __forceinline__ void issue_apron16(const _Float16* xb, int t0, int le
     }
 }
 
-template <int C, int W, int NTHREADS>
+template <int C, int W, int NTHREADS, int OPF = OP_BF16>
 __device__ __forceinline__ void commit_apron16(const u32x4 (&raw)[ApronLoad<C, NTHREADS>::PER], char* T0, int RS,
                                                int t0, int len, int g1) {
     using AL = ApronLoad<C, NTHREADS>;
@@ -288,7 +322,7 @@ __device__ __forceinline__ void commit_apron16(const u32x4 (&raw)[ApronLoad<C, N
         const int g = t0 + row;
         f32x4 a, b;
         unpack8_f16(raw[k], a, b);
-        *(u32x4*)(T0 + row * RS + u * 16) = pack8_bf16_lrelu(a, b, 0.1f, g >= 0 && g < len);
+        *(u32x4*)(T0 + row * RS + u * 16) = pack8_bf16_lrelu<OPF, true>(a, b, 0.1f, g >= 0 && g < len);
     }
 }
 
@@ -404,9 +438,11 @@ __device__ __forceinline__ void store_window16(_Float16* ob, const char* T0, int
 // hand-over to a next pair drop out).
 // X3: split bf16 operands (MV_PREC_BF16X3), float32 window IO; the tiles hold (hi, lo) pairs, every conv runs three
 // K steps per k-chunk (mma_pass), and the first pair's apron rows are loaded as float32.
-template <int C, int WM, int WN, int TN, bool IO16X = false, bool ONE = false, bool X3 = false>
+// OPF: operand format of the tiles and weights (OP_BF16 / OP_F16, conv_mfma.h)
+template <int C, int WM, int WN, int TN, bool IO16X = false, bool ONE = false, bool X3 = false, int OPF = OP_BF16>
 __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbParams p) {
     static_assert(!(X3 && IO16X), "split operands keep float32 activations between kernels");
+    static_assert(!(X3 && OPF != OP_BF16), "split operands are bfloat16");
     constexpr int TM = C / 16 / WM;
     constexpr int W = 16 * TN * WN;
     constexpr int NTHREADS = WM * WN * 64;
@@ -481,7 +517,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
         issue_window16<C, W, NTHREADS>((const _Float16*)p.x + (long long)b * p.batch_stride, t0, len, raw);
         issue_apron16<C, W, NTHREADS>((const _Float16*)p.x + (long long)b * p.batch_stride, t0, len, p.g1, rawa);
         commit_raw16<C, W, NTHREADS>(raw, A0, RS, t0, len);
-        commit_apron16<C, W, NTHREADS>(rawa, A0, RS, t0, len, p.g1);
+        commit_apron16<C, W, NTHREADS, OPF>(rawa, A0, RS, t0, len, p.g1);
         __syncthreads();
     }
     MV_LAP(tr, TR_SETUP);
@@ -510,7 +546,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
                 unpack8_f16(rawq[tn], X[0][tn], X[1][tn]);
-                *(u32x4*)(A0 + frag0 + tn * FRAG_TN) = pack8_bf16(lrelu4(X[0][tn], 0.1f), lrelu4(X[1][tn], 0.1f));
+                *(u32x4*)(A0 + frag0 + tn * FRAG_TN) = pack8_lrelu<OPF, true>(X[0][tn], X[1][tn], 0.1f);
             }
         } else {
 #pragma unroll
@@ -527,7 +563,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
                     if constexpr (X3)
                         store4_x3<C>(A0 + n * RS + ch * 2, lrelu4(q, 0.1f), in_seq);
                     else
-                        *(unsigned long long*)(A0 + n * RS + ch * 2) = pack4_bf16_lrelu(q, 0.1f, in_seq);
+                        *(unsigned long long*)(A0 + n * RS + ch * 2) = pack4_bf16_lrelu<OPF>(q, 0.1f, in_seq);
                 }
             }
             if constexpr (X3) {
@@ -570,7 +606,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = bias[tm];
-            conv_window<TM, TN, 4, X3>(acc, A0 + ((wn * TN * 16 + lr) - pad1) * RS + lg * 16, RS, p.K, d, NKC,
+            conv_window<TM, TN, 4, X3, OPF>(acc, A0 + ((wn * TN * 16 + lr) - pad1) * RS + lg * 16, RS, p.K, d, NKC,
                                        (const u32x4*)p.w1[m] + woff, mtile_stride, &wpre);
             MV_LAP(tr, TR_KLOOP);
             lds_bias(bias, bias_s, 2 * m + 1, C, chl);
@@ -595,13 +631,13 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
             } else if (interior) {
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
-                    *(u32x4*)(Y0 + frag0 + tn * FRAG_TN) = pack8_bf16(lrelu4(acc[0][tn], 0.1f), lrelu4(acc[1][tn], 0.1f));
+                    *(u32x4*)(Y0 + frag0 + tn * FRAG_TN) = pack8_lrelu<OPF>(acc[0][tn], acc[1][tn], 0.1f);
             } else {
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) {
                     const int g = t0 + (wn * TN + tn) * 16 + lr;
                     *(u32x4*)(Y0 + frag0 + tn * FRAG_TN) =
-                        pack8_bf16_lrelu(acc[0][tn], acc[1][tn], 0.1f, g >= 0 && g < len);
+                        pack8_bf16_lrelu<OPF>(acc[0][tn], acc[1][tn], 0.1f, g >= 0 && g < len);
                 }
             }
             MV_LAP(tr, TR_EPI);
@@ -609,7 +645,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
             MV_LAP(tr, TR_BARRIER);
             if (pf) {
                 commit_raw16<C, W, NTHREADS>(raw, A0, RS, t0n, lenn);
-                commit_apron16<C, W, NTHREADS>(rawa, A0, RS, t0n, lenn, p.g1);
+                commit_apron16<C, W, NTHREADS, OPF>(rawa, A0, RS, t0n, lenn, p.g1);
             }
             MV_LAP(tr, TR_LOADX);
             const int m_next = m + 1 < npair ? m + 1 : 0;
@@ -618,7 +654,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) X[tm][tn] += bias[tm];
-            conv_window<TM, TN, 4, X3>(X, Y0 + ((wn * TN * 16 + lr) - pad2) * RS + lg * 16, RS, p.K, 1, NKC,
+            conv_window<TM, TN, 4, X3, OPF>(X, Y0 + ((wn * TN * 16 + lr) - pad2) * RS + lg * 16, RS, p.K, 1, NKC,
                                        (const u32x4*)p.w2[m] + woff, mtile_stride, &wpre);
             MV_LAP(tr, TR_KLOOP);
             lds_bias(bias, bias_s, 2 * m_next, C, chl);
@@ -632,7 +668,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_rb_kernel(const FusedRbPara
                                      interior || (g >= 0 && g < len));
                     else
                         *(u32x4*)(A0 + frag0 + tn * FRAG_TN) =
-                            pack8_bf16_lrelu(X[0][tn], X[1][tn], 0.1f, interior || (g >= 0 && g < len));
+                            pack8_bf16_lrelu<OPF>(X[0][tn], X[1][tn], 0.1f, interior || (g >= 0 && g < len));
                 }
             }
         }
@@ -731,7 +767,7 @@ struct FusedStageParams {
 
 // IO16 (p.io16) and POST (p.post_w != null) are compile-time: with the four variants in one function the
 // register allocator budgets for the union of their live ranges and spills ~50 VGPRs in the one that runs.
-template <int C, int WM, int WN, int TN, bool IO16, bool POST>
+template <int C, int WM, int WN, int TN, bool IO16, bool POST, int OPF = OP_BF16>
 __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedStageParams p) {
     constexpr int TM = C / 16 / WM;
     constexpr int W = 16 * TN * WN;
@@ -799,7 +835,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
         issue_window16<C, W, NTHREADS>(xs, out0 - p.H, len, raw);
         issue_apron16<C, W, NTHREADS>(xs, out0 - p.H, len, p.g1[0], rawa);
         commit_raw16<C, W, NTHREADS>(raw, A0, RS, out0 - p.H, len);
-        commit_apron16<C, W, NTHREADS>(rawa, A0, RS, out0 - p.H, len, p.g1[0]);
+        commit_apron16<C, W, NTHREADS, OPF>(rawa, A0, RS, out0 - p.H, len, p.g1[0]);
         __syncthreads();
     }
     MV_LAP(tr, TR_SETUP);
@@ -845,7 +881,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) {
                     unpack8_f16(rawq[tn], X[0][tn], X[1][tn]);
-                    *(u32x4*)(A0 + frag0 + tn * FRAG_TN) = pack8_bf16(lrelu4(X[0][tn], 0.1f), lrelu4(X[1][tn], 0.1f));
+                    *(u32x4*)(A0 + frag0 + tn * FRAG_TN) = pack8_lrelu<OPF, true>(X[0][tn], X[1][tn], 0.1f);
                 }
             } else {
                 if (j > 0 || v != walk.v0) __syncthreads();  // every wave is done with the tiles
@@ -860,7 +896,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
                         f32x4 q = {0.f, 0.f, 0.f, 0.f};
                         if (in_seq) q = ld4(xb, (long long)g * C + ch, 0);
                         X[tm][tn] = q;
-                        *(unsigned long long*)(A0 + n * RS + ch * 2) = pack4_bf16_lrelu(q, 0.1f, in_seq);
+                        *(unsigned long long*)(A0 + n * RS + ch * 2) = pack4_bf16_lrelu<OPF>(q, 0.1f, in_seq);
                     }
                 }
             }
@@ -879,7 +915,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = bias[tm];
-                conv_window<TM, TN, ADEPTH>(acc, A0 + ((wn * TN * 16 + lr) - pad1) * RS + lg * 16, RS, K, d, NKC,
+                conv_window<TM, TN, ADEPTH, false, OPF>(acc, A0 + ((wn * TN * 16 + lr) - pad1) * RS + lg * 16, RS, K, d, NKC,
                                     (const u32x4*)p.w1[j][m] + woff, mtile_stride, &wpre);
                 MV_LAP(tr, TR_KLOOP);
                 lds_bias(bias, bias_s, (j * 3 + m) * 2 + 1, C, chl);
@@ -901,13 +937,13 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn)
                         *(u32x4*)(Y0 + frag0 + tn * FRAG_TN) =
-                            pack8_bf16(lrelu4(acc[0][tn], 0.1f), lrelu4(acc[1][tn], 0.1f));
+                            pack8_lrelu<OPF>(acc[0][tn], acc[1][tn], 0.1f);
                 } else {
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn) {
                         const int g = t0 + (wn * TN + tn) * 16 + lr;
                         *(u32x4*)(Y0 + frag0 + tn * FRAG_TN) =
-                            pack8_bf16_lrelu(acc[0][tn], acc[1][tn], 0.1f, g >= 0 && g < len);
+                            pack8_bf16_lrelu<OPF>(acc[0][tn], acc[1][tn], 0.1f, g >= 0 && g < len);
                     }
                 }
                 MV_LAP(tr, TR_EPI);
@@ -915,7 +951,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
                 MV_LAP(tr, TR_BARRIER);
                 if (pf) {
                     commit_raw16<C, W, NTHREADS>(raw, A0, RS, t0pf, lenpf);
-                    commit_apron16<C, W, NTHREADS>(rawa, A0, RS, t0pf, lenpf, g1pf);
+                    commit_apron16<C, W, NTHREADS, OPF>(rawa, A0, RS, t0pf, lenpf, g1pf);
                 }
                 MV_LAP(tr, TR_LOADX);
                 // x + bias + conv2(...): the K loop accumulates into the residual registers themselves
@@ -923,7 +959,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn) X[tm][tn] += bias[tm];
-                conv_window<TM, TN, ADEPTH>(X, Y0 + ((wn * TN * 16 + lr) - pad2) * RS + lg * 16, RS, K, 1, NKC,
+                conv_window<TM, TN, ADEPTH, false, OPF>(X, Y0 + ((wn * TN * 16 + lr) - pad2) * RS + lg * 16, RS, K, 1, NKC,
                                     (const u32x4*)p.w2[j][m] + woff, mtile_stride, &wpre);
                 MV_LAP(tr, TR_KLOOP);
                 {
@@ -939,7 +975,7 @@ __global__ __launch_bounds__(WM* WN * 64) void fused_stage_kernel(const FusedSta
                     for (int tn = 0; tn < TN; ++tn) {
                         const int g = t0 + (wn * TN + tn) * 16 + lr;
                         *(u32x4*)(A0 + frag0 + tn * FRAG_TN) =
-                            pack8_bf16_lrelu(X[0][tn], X[1][tn], 0.1f, interior || (g >= 0 && g < len));
+                            pack8_bf16_lrelu<OPF>(X[0][tn], X[1][tn], 0.1f, interior || (g >= 0 && g < len));
                     }
                 }
             }

@@ -92,6 +92,19 @@ static const FusedCfg kFused[] = {
     MV_FUSED_CFG(128, 4, 2, 7, 3),
     MV_FUSED_CFG(256, 8, 1, 7, 1),
 };
+// float16 operands (MV_PREC_F16): the same kernels, tiles and launch shapes
+#define MV_FUSED_CFG_F16(C, WM, WN, TN, NPAIR)                                                                     \
+    {                                                                                                              \
+        C, WM, WN, TN, NPAIR, fused_rb_kernel<C, WM, WN, TN, false, false, false, OP_F16>,                          \
+            fused_rb_kernel<C, WM, WN, TN, true, false, false, OP_F16>,                                             \
+            fused_rb_kernel<C, WM, WN, TN, true, true, false, OP_F16>, false                                        \
+    }
+static const FusedCfg kFusedF16[] = {
+    MV_FUSED_CFG_F16(32, 1, 8, 6, 3),
+    MV_FUSED_CFG_F16(64, 2, 4, 7, 3),
+    MV_FUSED_CFG_F16(128, 4, 2, 7, 3),
+    MV_FUSED_CFG_F16(256, 8, 1, 7, 1),
+};
 // split operands: the (hi, lo) tiles take twice the LDS per row, so the windows are half as long; C = 256 does not
 // fit a useful window and stays layer by layer
 #define MV_FUSED_X3(C, WM, WN, TN, NPAIR) \
@@ -113,7 +126,7 @@ static const FusedCfg* fused_cfg_for(int Cp, int precision) {
             if (f.C == Cp) return &f;
         return nullptr;
     }
-    for (const FusedCfg& f : kFused)
+    for (const FusedCfg& f : precision == MV_PREC_F16 ? kFusedF16 : kFused)
         if (f.C == Cp) return &f;
     return nullptr;
 }
@@ -147,28 +160,47 @@ static const StageCfg kStage[] = {
     MV_STAGE_CFG(32, 1, 8, 6),
     MV_STAGE_CFG(64, 2, 4, 7),
 };
-static const StageCfg* stage_cfg_for(int Cp) {
-    for (const StageCfg& f : kStage)
+static const StageCfg kStageF16[] = {
+#define MV_STAGE_CFG_F16(C, WM, WN, TN)                                                    \
+    {                                                                                      \
+        C, WM, WN, TN, {                                                                   \
+            {fused_stage_kernel<C, WM, WN, TN, false, false, OP_F16>,                      \
+             fused_stage_kernel<C, WM, WN, TN, false, true, OP_F16>},                      \
+                {fused_stage_kernel<C, WM, WN, TN, true, false, OP_F16>,                   \
+                 fused_stage_kernel<C, WM, WN, TN, true, true, OP_F16>},                   \
+        }                                                                                  \
+    }
+    MV_STAGE_CFG_F16(32, 1, 8, 6),
+    MV_STAGE_CFG_F16(64, 2, 4, 7),
+};
+static const StageCfg* stage_cfg_for(int Cp, int precision) {
+    for (const StageCfg& f : precision == MV_PREC_F16 ? kStageF16 : kStage)
         if (f.C == Cp) return &f;
     return nullptr;
 }
+// the 16-bit operand modes that share kernels, float16 activation storage and launch structure
+static bool is_op16(int precision) { return precision == MV_PREC_BF16 || precision == MV_PREC_F16; }
 
 int init_fused_attributes() {
     for (const FusedCfg& f : kFusedX3)
         MV_HIP(hipFuncSetAttribute((const void*)f.k, hipFuncAttributeMaxDynamicSharedMemorySize, kFusedMaxLds));
-    for (const FusedCfg& f : kFused) {
-        MV_HIP(hipFuncSetAttribute((const void*)f.k, hipFuncAttributeMaxDynamicSharedMemorySize, kFusedMaxLds));
-        if (f.k16)
-            MV_HIP(hipFuncSetAttribute((const void*)f.k16, hipFuncAttributeMaxDynamicSharedMemorySize, kFusedMaxLds));
-        if (f.k16_one)
-            MV_HIP(hipFuncSetAttribute((const void*)f.k16_one, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       kFusedMaxLds));
-    }
-    for (const StageCfg& f : kStage)
-        for (int a = 0; a < 2; ++a)
-            for (int b = 0; b < 2; ++b)
-                MV_HIP(hipFuncSetAttribute((const void*)f.k[a][b], hipFuncAttributeMaxDynamicSharedMemorySize,
+    for (const FusedCfg* tab : {kFused, kFusedF16})
+        for (int i = 0; i < (int)(sizeof(kFused) / sizeof(kFused[0])); ++i) {
+            const FusedCfg& f = tab[i];
+            MV_HIP(hipFuncSetAttribute((const void*)f.k, hipFuncAttributeMaxDynamicSharedMemorySize, kFusedMaxLds));
+            if (f.k16)
+                MV_HIP(hipFuncSetAttribute((const void*)f.k16, hipFuncAttributeMaxDynamicSharedMemorySize, kFusedMaxLds));
+            if (f.k16_one)
+                MV_HIP(hipFuncSetAttribute((const void*)f.k16_one, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            kFusedMaxLds));
+        }
+    static_assert(sizeof(kFused) == sizeof(kFusedF16) && sizeof(kStage) == sizeof(kStageF16), "one entry per format");
+    for (const StageCfg* tab : {kStage, kStageF16})
+        for (int i = 0; i < (int)(sizeof(kStage) / sizeof(kStage[0])); ++i)
+            for (int a = 0; a < 2; ++a)
+                for (int b = 0; b < 2; ++b)
+                    MV_HIP(hipFuncSetAttribute((const void*)tab[i].k[a][b], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               kFusedMaxLds));
     return MV_OK;
 }
 
@@ -504,8 +536,9 @@ static int launch_fused_rb(const FusedCfg& fc, const RbPair* pairs, int m0, int 
     FusedKernel kern = one ? fc.k16_one : io16 ? fc.k16 : fc.k;
     if (prof) {
         char nm[128], dt[32];  // the symbol as rocprofv3 prints it + which of its launches
-        snprintf(nm, sizeof nm, "void mv::fused_rb_kernel<%d, %d, %d, %d, %s, %s, %s>(mv::FusedRbParams)", fc.C, fc.WM,
-                 fc.WN, fc.TN, io16 ? "true" : "false", one ? "true" : "false", fc.x3 ? "true" : "false");
+        const int opf = &fc >= kFusedF16 && &fc < kFusedF16 + sizeof(kFusedF16) / sizeof(kFusedF16[0]) ? OP_F16 : OP_BF16;
+        snprintf(nm, sizeof nm, "void mv::fused_rb_kernel<%d, %d, %d, %d, %s, %s, %s, %d>(mv::FusedRbParams)", fc.C, fc.WM,
+                 fc.WN, fc.TN, io16 ? "true" : "false", one ? "true" : "false", fc.x3 ? "true" : "false", opf);
         snprintf(dt, sizeof dt, "k=%d", K);
         prof->begin(stream, nm, macs * rpf, dt);
     }
@@ -585,8 +618,9 @@ static int launch_fused_stage(const StageCfg& sc, const HifiganHandle* h, int i,
     if (wav) MV_HIP(hipMemsetAsync(wav, 0, (size_t)B * rows * (out_format == MV_OUT_PCM16 ? 2 : 4), stream));
     if (prof) {
         char nm[128];
-        snprintf(nm, sizeof nm, "void mv::fused_stage_kernel<%d, %d, %d, %d, %s, %s>(mv::FusedStageParams)", sc.C, sc.WM,
-                 sc.WN, sc.TN, io16 ? "true" : "false", wav ? "true" : "false");
+        snprintf(nm, sizeof nm, "void mv::fused_stage_kernel<%d, %d, %d, %d, %s, %s, %d>(mv::FusedStageParams)", sc.C, sc.WM,
+                 sc.WN, sc.TN, io16 ? "true" : "false", wav ? "true" : "false",
+                 h->precision == MV_PREC_F16 ? OP_F16 : OP_BF16);
         prof->begin(stream, nm, macs * rpf, wav ? "+conv_post" : nrb < c.num_kernels ? "first ResBlocks" : "");
     }
     hipLaunchKernelGGL(sc.k[io16 ? 1 : 0][wav ? 1 : 0], grid, dim3(sc.threads()), lds, stream, p);
@@ -606,7 +640,7 @@ static int hifigan_forward(HifiganHandle* h, const float* mel, const int32_t* le
     int rc;
     Profiler* prof = h->prof.on ? &h->prof : nullptr;
     // bf16 mode: activations between kernels are float16 (see ld4/st4 in conv_mfma.h); fp32 mode: float32
-    const int io16 = h->precision == MV_PREC_BF16 ? h->opt.io16 : 0;
+    const int io16 = is_op16(h->precision) ? h->opt.io16 : 0;
     const size_t bt = (size_t)B * Tmax;
     char* ws = (char*)workspace;
     float* X0 = (float*)ws;
@@ -646,7 +680,7 @@ static int hifigan_forward(HifiganHandle* h, const float* mel, const int32_t* le
                                Tmax, stream, prof, io16, io16)))
             return rc;
         const FusedCfg* fc = h->precision != MV_PREC_FP32 && h->opt.fuse >= 1 ? fused_cfg_for(Cp, h->precision) : nullptr;
-        const StageCfg* sc = h->precision == MV_PREC_BF16 && h->opt.fuse >= 2 ? stage_cfg_for(Cp) : nullptr;
+        const StageCfg* sc = is_op16(h->precision) && h->opt.fuse >= 2 ? stage_cfg_for(Cp, h->precision) : nullptr;
         int j0 = 0;  // ResBlocks [0, j0) are done by a stage launch
         if (sc) {
             const bool last = i == h->nstage - 1;
@@ -745,7 +779,7 @@ int mv_hifigan_create(const mv_hifigan_cfg* cfg, const mv_tensor* weights, int n
         return MV_EINVAL;
     }
     *out = nullptr;
-    if (precision != MV_PREC_FP32 && precision != MV_PREC_BF16 && precision != MV_PREC_BF16X3) {
+    if (precision != MV_PREC_FP32 && precision != MV_PREC_BF16 && precision != MV_PREC_BF16X3 && precision != MV_PREC_F16) {
         set_error("mv_hifigan_create: unknown precision %d", precision);
         return MV_EINVAL;
     }

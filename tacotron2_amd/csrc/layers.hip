@@ -48,9 +48,19 @@ static inline uint16_t f2bf(float x) {
     return (uint16_t)(u >> 16);
 }
 
+// float32 -> float16 bits, round to nearest even, saturating at +-65504 (the kernels' own conversions saturate too)
+static inline uint16_t f2h(float x) {
+    if (x != x) return 0x7e00;
+    x = x > 65504.f ? 65504.f : (x < -65504.f ? -65504.f : x);
+    const _Float16 h = (_Float16)x;
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
+
 int build_layer(Layer* L, const std::vector<SrcSpec>& srcs, int M, const std::vector<float>& bias, int prec, int epi,
                 int force_cfg, bool one_pass) {
-    const bool bf16 = prec != MV_PREC_FP32, x3 = prec == MV_PREC_BF16X3;
+    const bool bf16 = prec != MV_PREC_FP32, x3 = prec == MV_PREC_BF16X3, f16 = prec == MV_PREC_F16;
     const int CH = bf16 ? 32 : 16;
     const int ES = bf16 && !x3 ? 2 : 4;  // LDS bytes per staged element (x3: a bf16 pair)
     const int KV = x3 ? 3 : 1;           // K steps per real k-chunk (x3: hi*hi, hi*lo, lo*hi)
@@ -61,6 +71,7 @@ int build_layer(Layer* L, const std::vector<SrcSpec>& srcs, int M, const std::ve
     L->M = M;
     L->bf16 = bf16;
     L->x3 = x3;
+    L->opf = f16 ? OP_F16 : OP_BF16;
     L->epi = epi;
     L->cfg = force_cfg >= 0 ? force_cfg : default_cfg(M);
     const TileCfg& tc = kTileCfgs[L->cfg];
@@ -145,6 +156,7 @@ int build_layer(Layer* L, const std::vector<SrcSpec>& srcs, int M, const std::ve
                         uint32_t* dst = &packed[(((size_t)mt * L->steps_total + step) * 64 + lane) * 4];
                         if (bf16) {
                             auto part = [&](float w) -> uint32_t {
+                                if (f16) return f2h(w);
                                 const uint16_t h = f2bf(w);
                                 if (!want_lo) return h;
                                 uint32_t u = (uint32_t)h << 16;
@@ -183,18 +195,18 @@ void free_layer(Layer* L) {
 // ---- kernel table ---------------------------------------------------------------------------
 typedef void (*ConvKernel)(const ConvParams);
 
-template <bool BF16, int EPI, bool X3>
+template <bool BF16, int EPI, bool X3, int OPF = OP_BF16>
 static ConvKernel kernel_for(int cfg) {
     switch (cfg) {
-        case 0: return conv_cl_kernel<BF16, 4, 4, 4, 1, EPI, X3>;
-        case 1: return conv_cl_kernel<BF16, 4, 8, 4, 1, EPI, X3>;
-        case 2: return conv_cl_kernel<BF16, 4, 4, 2, 2, EPI, X3>;
-        case 3: return conv_cl_kernel<BF16, 4, 4, 1, 4, EPI, X3>;
-        case 4: return conv_cl_kernel<BF16, 2, 4, 1, 4, EPI, X3>;
-        case 5: return conv_cl_kernel<BF16, 2, 8, 1, 4, EPI, X3>;
-        case 6: return conv_cl_kernel<BF16, 4, 8, 1, 4, EPI, X3>;
-        case 7: return conv_cl_kernel<BF16, 4, 8, 2, 2, EPI, X3>;
-        case 8: return conv_cl_kernel<BF16, 4, 8, 4, 2, EPI, X3>;
+        case 0: return conv_cl_kernel<BF16, 4, 4, 4, 1, EPI, X3, OPF>;
+        case 1: return conv_cl_kernel<BF16, 4, 8, 4, 1, EPI, X3, OPF>;
+        case 2: return conv_cl_kernel<BF16, 4, 4, 2, 2, EPI, X3, OPF>;
+        case 3: return conv_cl_kernel<BF16, 4, 4, 1, 4, EPI, X3, OPF>;
+        case 4: return conv_cl_kernel<BF16, 2, 4, 1, 4, EPI, X3, OPF>;
+        case 5: return conv_cl_kernel<BF16, 2, 8, 1, 4, EPI, X3, OPF>;
+        case 6: return conv_cl_kernel<BF16, 4, 8, 1, 4, EPI, X3, OPF>;
+        case 7: return conv_cl_kernel<BF16, 4, 8, 2, 2, EPI, X3, OPF>;
+        case 8: return conv_cl_kernel<BF16, 4, 8, 4, 2, EPI, X3, OPF>;
     }
     return nullptr;
 }
@@ -205,12 +217,15 @@ static ConvKernel pick_kernel(int prec, int epi, int cfg) {
         return epi == EPI_GATE ? kernel_for<true, EPI_GATE, true>(cfg) : kernel_for<true, EPI_LINEAR, true>(cfg);
     if (prec == MV_PREC_BF16)
         return epi == EPI_GATE ? kernel_for<true, EPI_GATE, false>(cfg) : kernel_for<true, EPI_LINEAR, false>(cfg);
+    if (prec == MV_PREC_F16)
+        return epi == EPI_GATE ? kernel_for<true, EPI_GATE, false, OP_F16>(cfg)
+                               : kernel_for<true, EPI_LINEAR, false, OP_F16>(cfg);
     return epi == EPI_GATE ? kernel_for<false, EPI_GATE, false>(cfg) : kernel_for<false, EPI_LINEAR, false>(cfg);
 }
 
 int init_kernel_attributes() {
     // per device: allow the full 160 KiB of dynamic LDS
-    for (int prec = 0; prec < 3; ++prec)
+    for (int prec = 0; prec < 4; ++prec)
         for (int epi = 0; epi < 2; ++epi)
             for (int c = 0; c < kNumTileCfgs; ++c) {
                 ConvKernel k = pick_kernel(prec, epi, c);
@@ -255,8 +270,8 @@ std::string layer_kernel_name(const Layer& L) {
     const TileCfg& tc = kTileCfgs[L.cfg];
     char buf[128];
     // the symbol as rocprofv3 prints it
-    snprintf(buf, sizeof buf, "void mv::conv_cl_kernel<%s, %d, %d, %d, %d, %d, %s>(mv::ConvParams)",
-             L.bf16 ? "true" : "false", tc.TM, tc.TN, tc.WM, tc.WN, L.epi, L.x3 ? "true" : "false");
+    snprintf(buf, sizeof buf, "void mv::conv_cl_kernel<%s, %d, %d, %d, %d, %d, %s, %d>(mv::ConvParams)",
+             L.bf16 ? "true" : "false", tc.TM, tc.TN, tc.WM, tc.WN, L.epi, L.x3 ? "true" : "false", L.opf);
     return buf;
 }
 
@@ -345,7 +360,8 @@ int launch_layer(const Layer& L, const SrcBind* srcs, int nsrc, const LaunchArgs
         grid = dim3((nx + 7) / 8 * 8 * ny, 1, (unsigned)a.B);
     }
     dim3 block(tc.WM * tc.WN * 64);
-    ConvKernel k = pick_kernel(L.x3 ? MV_PREC_BF16X3 : L.bf16 ? MV_PREC_BF16 : MV_PREC_FP32, L.epi, L.cfg);
+    ConvKernel k = pick_kernel(L.x3 ? MV_PREC_BF16X3 : L.opf == OP_F16 ? MV_PREC_F16 : L.bf16 ? MV_PREC_BF16 : MV_PREC_FP32,
+                               L.epi, L.cfg);
     if (prof) prof->begin(stream, layer_kernel_name(L), L.alg_macs_per_n * a.n_rows_per_frame);
     hipLaunchKernelGGL(k, grid, block, L.lds_bytes, stream, p);
     if (prof) prof->end(stream);

@@ -167,7 +167,7 @@ int mv_postnet_create(const mv_postnet_cfg* cfg, const mv_tensor* weights, int n
         return MV_EINVAL;
     }
     *out = nullptr;
-    if (precision != MV_PREC_FP32 && precision != MV_PREC_BF16 && precision != MV_PREC_BF16X3) {
+    if (precision != MV_PREC_FP32 && precision != MV_PREC_BF16 && precision != MV_PREC_BF16X3 && precision != MV_PREC_F16) {
         set_error("mv_postnet_create: unknown precision %d", precision);
         return MV_EINVAL;
     }

@@ -573,7 +573,8 @@ static int waveglow_build(WaveglowHandle* h, WeightMap& W) {
             for (int m = 0; m < 2 * C; ++m) bias[m] = ib->data[orig(m)] + cbd[orig(m)];
             // bf16: 256 x 128 tiles (a weight fragment feeds 8 MFMAs instead of 4: the L1 weight stream paces
             // the 256 x 64 tile)
-            const int wide = bf16 && (2 * C) % 256 == 0 ? 1 : -1;
+            const bool op16 = bf16 || h->precision == MV_PREC_F16;  // (float16 operands: the reference's split, layer kernels)
+            const int wide = op16 && (2 * C) % 256 == 0 ? 1 : -1;
             if ((rc = build_layer(&f.in_layers[i], {sh, sc}, 2 * C, bias, prec, EPI_GATE, wide))) return rc;
             f.in_layers[i].alg_macs_per_n = (double)2 * C * C * ks + (double)2 * C * h->ncond;
             if (h->gg) {
@@ -596,7 +597,7 @@ static int waveglow_build(WaveglowHandle* h, WeightMap& W) {
             sa.dil = 1;
             sa.pad_left = 0;
             sa.w = [=](int m, int, int ci) -> float { return ci < C ? rwd[(size_t)m * C + ci] : 0.f; };
-            const int rwide = bf16 && rsC % 256 == 0 ? 1 : -1;
+            const int rwide = op16 && rsC % 256 == 0 ? 1 : -1;
             if (!fold) {
                 if ((rc = build_layer(&f.res_skip[i], {sa}, rsC, rb->data, prec, EPI_LINEAR, rwide))) return rc;
                 f.res_skip[i].alg_macs_per_n = (double)rsC * C;
@@ -919,7 +920,7 @@ int mv_waveglow_create(const mv_waveglow_cfg* cfg, const mv_tensor* weights, int
         return MV_EINVAL;
     }
     *out = nullptr;
-    if (precision != MV_PREC_FP32 && precision != MV_PREC_BF16 && precision != MV_PREC_BF16X3) {
+    if (precision != MV_PREC_FP32 && precision != MV_PREC_BF16 && precision != MV_PREC_BF16X3 && precision != MV_PREC_F16) {
         set_error("mv_waveglow_create: unknown precision %d", precision);
         return MV_EINVAL;
     }

@@ -66,7 +66,7 @@ def main(argv=None):
     ap.add_argument("--mels", default=None, help="directory of parameter files (*.WAVEGLOW / *.mel)")
     ap.add_argument("--n", type=int, default=1000, help="synthetic corpus size when --mels is not given")
     ap.add_argument("--seed", type=int, default=1234)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "fp32", "bf16x3"])
     ap.add_argument("--max_batch", type=int, default=32)
     ap.add_argument("--width", type=int, default=64, help="max frame spread inside a bucket")
     ap.add_argument("--out_dir", default=None)

@@ -162,7 +162,7 @@ def main(argv=None):
     ap.add_argument("--n", type=int, default=256)
     ap.add_argument("--vocoder", default="synthetic-hifigan")
     ap.add_argument("--tc2", default=None, help="Tacotron2 checkpoint (state_dict); default: synthetic weights")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "bf16x3"], help="Postnet / vocoder precision")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "fp32", "bf16x3"], help="Postnet / vocoder precision")
     ap.add_argument("--tc2_dtype", default="fp32", choices=["fp32", "bf16"], help="PyTorch dtype of the mel producer")
     ap.add_argument("--max_batch", type=int, default=512,
                     help="utterances per decode bucket (capped so that every rank gets at least two buckets)")

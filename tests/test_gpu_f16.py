@@ -1,0 +1,150 @@
+"""MV_PREC_F16 (include/melvoc.h): float16 MFMA operands through the kernels of MV_PREC_BF16 -- same cycles per
+v_mfma_f32_16x16x32, 11 significant bits per operand instead of 8.  It exists because bf16's margin over BASELINE.json's
+40 dB bar is thin on synthetic weights (tests/test_gpu_bf16_margin.py: 40.2 dB worst case for HiFi-GAN) and no real
+checkpoint is available offline to show it holds there.  Bars here: the reference's golden vectors at >= 50 dB, the
+margin suite (7 weight seeds incl. heavy-tailed, loud / half-floor mels) at >= 50 dB worst case against the library's
+pinned fp32 mode, every kernel structure (mv_options) at the same bar, and saturation instead of inf / NaN when an
+operand leaves float16's range."""
+import copy
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from tacotron2_amd import _native, synth  # noqa: E402
+from tacotron2_amd.hifigan import AttrDict, Generator  # noqa: E402
+from tacotron2_amd.postnet import Postnet  # noqa: E402
+from tacotron2_amd.waveglow import WaveGlow  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from test_gpu_bf16_margin import CASES, _heavy, _mels, _snr  # noqa: E402
+
+F16_BAR_DB = 50.0
+
+
+def _gen(prec, seed=0, options=None, state=None):
+    g = Generator(AttrDict(synth.HIFIGAN_V1), precision=prec, options=options)
+    st = state if state is not None else synth.hifigan_state(synth.HIFIGAN_V1, seed)
+    g.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
+    return g.eval().cuda()
+
+
+@pytest.mark.parametrize("name,T", [("hifigan_v1_T64", 64), ("hifigan_v1_T500", 500)])
+def test_hifigan_f16_against_reference_golden(golden_dir, name, T):
+    d = np.load(os.path.join(golden_dir, name + ".npz"))
+    g = _gen("f16")
+    mel = torch.from_numpy(synth.synthetic_mel(T, int(d["mel_seed"]))).cuda()
+    y = g(mel[None])[0, 0].cpu().numpy()
+    assert _snr(d["wav"], y) >= F16_BAR_DB
+    # 2-D input (do_syn.py:391) and PCM16 (do_syn.py:389-394) go through the same path
+    assert np.array_equal(g(mel)[0].cpu().numpy(), y)
+    pcm = g(mel[None], out="pcm16")[0, 0].cpu().numpy()
+    assert np.array_equal(pcm, (32768.0 * y).astype(np.int32).astype(np.int16))
+
+
+def test_hifigan_f16_margin():
+    worst = (1e9, None)
+    for seed, heavy in CASES:
+        st = synth.hifigan_state(synth.HIFIGAN_V1, seed)
+        if heavy:
+            st = _heavy(st, seed)
+        mel = torch.from_numpy(_mels(96, 10 * seed)).cuda()
+        ref = _gen("fp32", state=st)(mel)[:, 0].cpu().numpy()
+        got = _gen("f16", state=st)(mel)[:, 0].cpu().numpy()
+        for b in range(3):
+            s = _snr(ref[b], got[b])
+            worst = min(worst, (s, (seed, heavy, b)))
+    print("hifigan f16 worst-case SNR %.1f dB at (seed, heavy-tailed, mel) = %s" % worst)
+    assert worst[0] >= F16_BAR_DB, worst
+
+
+@pytest.mark.parametrize("options", [None, {"fuse": 0}, {"fuse": 1}, {"io16": 0}, {"fuse": 1, "io16": 0},
+                                     {"fuse": 0, "io16": 0}], ids=lambda o: str(o))
+def test_hifigan_f16_under_options_and_ragged(options, golden_dir):
+    d = np.load(os.path.join(golden_dir, "hifigan_v1_T64.npz"))
+    g = _gen("f16", options=options)
+    mel = torch.from_numpy(synth.synthetic_mel(64, int(d["mel_seed"]))).cuda()
+    assert _snr(d["wav"], g(mel[None])[0, 0].cpu().numpy()) >= F16_BAR_DB
+    lens = [64, 37, 5, 1]
+    x = torch.full((4, 80, 64), synth.MEL_PAD_VALUE)
+    for b, n in enumerate(lens):
+        x[b, :, :n] = torch.from_numpy(synth.synthetic_mel(n, 40 + b))
+    y = g(x.cuda(), lengths=lens)[:, 0].cpu().numpy()
+    for b, n in enumerate(lens):
+        solo = g(x[b:b + 1, :, :n].contiguous().cuda())[0, 0].cpu().numpy()
+        assert float(np.abs(solo - y[b, :n * 256]).max()) <= 1e-3, (b, n)
+        assert not y[b, n * 256:].any()
+
+
+def test_bench_batch_f16_against_fp32_mode():
+    """BASELINE configs[1] at full size under float16 operands, every utterance against the pinned fp32 mode."""
+    lengths = np.sort(synth.synthetic_lengths(32, 1234))[::-1].copy()
+    Tmax = int(lengths.max())
+    x = np.full((32, 80, Tmax), synth.MEL_PAD_VALUE, np.float32)
+    for b, T in enumerate(lengths):
+        x[b, :, :T] = synth.synthetic_mel(int(T), 1234000 + b)
+    xg, ln = torch.from_numpy(x).cuda(), torch.from_numpy(lengths.astype(np.int32)).cuda()
+    ref = _gen("fp32")(xg, lengths=ln)[:, 0].cpu().numpy()
+    got = _gen("f16")(xg, lengths=ln)[:, 0].cpu().numpy()
+    for b, T in enumerate(lengths):
+        n = int(T) * 256
+        assert _snr(ref[b, :n], got[b, :n]) >= F16_BAR_DB, b
+        assert not got[b, n:].any()
+
+
+def test_f16_operands_saturate():
+    """An operand beyond +-65504 is clamped where it is converted (bf16 has float32's range, float16 does not): a
+    convolution of huge inputs stays finite and equals the convolution of the clamped inputs."""
+    lib = _native.lib()
+    rng = np.random.default_rng(3)
+    B, L, Cin, Cout, K = 1, 40, 32, 32, 3
+    x = (rng.standard_normal((B, L, Cin)) * 4e5).astype(np.float32)  # most entries out of range
+    w = (rng.standard_normal((Cout, Cin, K)) * 1e-3).astype(np.float32)
+    bias = np.zeros(Cout, np.float32)
+    xg = torch.from_numpy(x).cuda()
+    yg = torch.zeros(B, L, Cout, device="cuda")
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+    rc = lib.mv_test_conv1d(xg.data_ptr(), None, B, L, Cin, fp(w), fp(bias), Cout, K, 1, 1.0, _native.PREC_F16,
+                            yg.data_ptr(), None)
+    _native.check(rc, "mv_test_conv1d")
+    y = yg.cpu().numpy()
+    assert np.isfinite(y).all()
+    xc = np.clip(x, -65504.0, 65504.0).astype(np.float16).astype(np.float64)
+    wc = w.astype(np.float16).astype(np.float64)
+    xp = np.pad(xc, ((0, 0), (1, 1), (0, 0)))
+    ref = sum(xp[:, k:k + L, :] @ wc[:, :, k].T for k in range(K))
+    assert np.abs(y - ref).max() <= 1e-3 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("c,name", [(64, "waveglow_c64_T16"), (256, "waveglow_c256_T64"), (512, "waveglow_c512_T16")])
+def test_waveglow_f16_against_reference_golden(golden_dir, c, name):
+    d = np.load(os.path.join(golden_dir, name + ".npz"))
+    cfg = copy.deepcopy(synth.WAVEGLOW_512)
+    cfg["WN_config"]["n_channels"] = c
+    B, T = int(d["B"]), int(d["T"])
+    m = WaveGlow.remove_weightnorm(WaveGlow(**cfg))
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.waveglow_state(cfg, int(d["weight_seed"])).items()})
+    m.cuda().eval()
+    m.precision = "f16"
+    mel = torch.from_numpy(np.stack([synth.synthetic_mel(T, int(d["mel_seed"]) + b) for b in range(B)])).cuda()
+    noise = [torch.from_numpy(n) for n in synth.waveglow_noise(cfg, B, T, int(d["noise_seed"]))]
+    assert _snr(d["wav"], m.infer(mel, sigma=float(d["sigma"]), noise=noise).cpu().numpy()) >= F16_BAR_DB
+
+
+def test_postnet_f16(golden_dir):
+    d = np.load(os.path.join(golden_dir, "postnet_tc2_ragged.npz"))
+    m = Postnet(synth.POSTNET_TC2, 0, precision="f16")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.postnet_state(synth.POSTNET_TC2, 0).items()}, strict=False)
+    m.eval().cuda()
+    lens = [int(n) for n in d["lengths"]]
+    x = torch.full((len(lens), 80, max(lens)), synth.MEL_PAD_VALUE)
+    for i, n in enumerate(lens):
+        x[i, :, :n] = torch.from_numpy(synth.synthetic_mel(n, int(d["mel_seed"]) + i))
+    s = m(x.cuda(), lengths=lens, add_input=True).cpu().numpy()
+    for i, n in enumerate(lens):
+        assert _snr(d[f"sum.{i}"], s[i, :, :n]) >= F16_BAR_DB
+        assert not s[i, :, n:].any()
