@@ -268,16 +268,27 @@ def tacotron2_case(name, n_text=23, seed=1234, lgs_max=0.3):
     spk, style = torch.tensor([[3]]), torch.tensor([[5]])
     out = ref.inference((text, spk, style), seed)
     mel, gate = out[0][0], out[2][0]
+    # second case, deterministic: the same model with the prenet's always-on dropout (model.py:136) at p = 0, so that
+    # a decode on ANOTHER device (other random streams) can be held against it -- tests/test_gpu_e2e.py
+    for d in ref.decoder:
+        if hasattr(d, "prenet"):
+            d.prenet.p_prenet_dropout = 0.0
+    out0 = ref.inference((text, spk, style), seed)
+    mel0, gate0 = out0[0][0], out0[2][0]
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), text=text.numpy(), spk=np.int64(3), style=np.int64(5),
                         seed=np.int64(seed), lgs_max=np.float64(lgs_max), mel=mel.numpy(), gate=gate.numpy(),
-                        contract=json.dumps(contract))
-    print(name, tuple(mel.shape), "mel rms %.4f" % float(mel.pow(2).mean().sqrt()))
+                        mel_nodrop=mel0.numpy(), gate_nodrop=gate0.numpy(), contract=json.dumps(contract))
+    print(name, tuple(mel.shape), "mel rms %.4f" % float(mel.pow(2).mean().sqrt()), "| dropout off:", tuple(mel0.shape),
+          "max |mel - mel_nodrop| %.3f" % float((mel - mel0).abs().max()))
 
 
 def main():
     os.makedirs(GOLD, exist_ok=True)
     if "--only-tacotron2" in sys.argv:
         tacotron2_case("tacotron2_tc2_decode")
+        return
+    if "--only-waveglow-c512-T64" in sys.argv:
+        waveglow_case("waveglow_c512_T64", synth.WAVEGLOW_512, 0, 64, 1, 1234, 1234, 0.666)
         return
     if "--only-postnet" in sys.argv:
         postnet_case("postnet_tc2_ragged", synth.POSTNET_TC2, 0, [40, 52, 64], 4321)
@@ -294,6 +305,8 @@ def main():
     wg64["WN_config"]["n_channels"] = 64
     waveglow_case("waveglow_c64_T16", wg64, 0, 16, 2, 1234, 1234, 0.666)
     waveglow_case("waveglow_c512_T16", synth.WAVEGLOW_512, 0, 16, 1, 1234, 1234, 0.666)
+    # several 128- / 256-row tiles, dilation 128 crossing tile edges (L = 32 T = 2048 steps)
+    waveglow_case("waveglow_c512_T64", synth.WAVEGLOW_512, 0, 64, 1, 1234, 1234, 0.666)
     wg256 = copy.deepcopy(synth.WAVEGLOW_512)
     wg256["WN_config"]["n_channels"] = 256  # the repo's own waveglow/config.json:37 width
     waveglow_case("waveglow_c256_T64", wg256, 0, 64, 1, 1234, 1234, 0.666)

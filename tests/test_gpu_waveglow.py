@@ -36,7 +36,8 @@ def _model(cfg, seed, precision):
     return m
 
 
-@pytest.mark.parametrize("c,name", [(64, "waveglow_c64_T16"), (256, "waveglow_c256_T64"), (512, "waveglow_c512_T16")])
+@pytest.mark.parametrize("c,name", [(64, "waveglow_c64_T16"), (256, "waveglow_c256_T64"), (512, "waveglow_c512_T16"),
+                                    (512, "waveglow_c512_T64")])  # T64: 2048 steps = 8 / 16 row tiles, dilation 128 across them
 def test_golden(golden_dir, c, name):
     d = np.load(os.path.join(golden_dir, name + ".npz"))
     cfg = _cfg(c)

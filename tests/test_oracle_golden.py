@@ -129,9 +129,10 @@ def test_c_oracle_waveglow(golden_dir, c, name):
             assert np.abs(sp - d["spect"][b]).max() < TOL
 
 
-def test_torch_ref_waveglow(golden_dir):
-    d = _load(golden_dir, "waveglow_c256_T64")
-    cfg = _wg_cfg(256)
+@pytest.mark.parametrize("c,name", [(256, "waveglow_c256_T64"), (512, "waveglow_c512_T64")])
+def test_torch_ref_waveglow(golden_dir, c, name):
+    d = _load(golden_dir, name)
+    cfg = _wg_cfg(c)
     st = synth.waveglow_state(cfg, int(d["weight_seed"]))
     B, T = int(d["B"]), int(d["T"])
     mel = np.stack([synth.synthetic_mel(T, int(d["mel_seed"]) + b) for b in range(B)])
