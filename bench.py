@@ -461,6 +461,8 @@ def run_rank(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.dry_run:
         # the launch / rendezvous / reduction path with no GPU: what tests/test_host_logic.py drives at world 2
+        if os.environ.get("BENCH_DRY_RUN_FAIL_RANK") == str(rank):  # (test hook: a rank that dies before the rendezvous)
+            return 3
         if world > 1:
             dist.init_process_group("gloo")
         t = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)

@@ -16,8 +16,12 @@
  *     The caller owns mel, lengths, noise, output and workspace (device memory).
  *   - a handle owns only its repacked weights; it is bound to the device it was created on and
  *     is not re-entrant (callers serialise calls on one handle; distinct handles are independent).
- *     The library keeps no process-global mutable state besides the per-thread error string and reads
- *     no environment variables: what can be tuned is in mv_options, per handle.
+ *     Process-global state: the per-thread error string, and ONE exception to "distinct handles are
+ *     independent" -- the static scratch of mv_hifigan_forward_static, a MV_STATIC_SCRATCH_BYTES device
+ *     array that is part of the library's code object (every GPU a process runs the library on holds a
+ *     copy from load to exit, used or not) and is shared by every handle and stream on that GPU: calls
+ *     of mv_hifigan_forward_static on one GPU must be serialised by the caller.  The library reads no
+ *     environment variables: what can be tuned is in mv_options, per handle.
  *   - the library needs a gfx950 device: there is no CPU fallback (mv_backend() == 1 always).
  */
 #ifndef MELVOC_H
@@ -157,7 +161,8 @@ MV_API int mv_hifigan_forward(mv_handle h, const float* mel, const int32_t* leng
  * loops such as do_tts.py-style streaming of short chunks, harnesses that forbid hipMalloc).  It has NO counterpart
  * in the reference.  Same arguments and results as mv_hifigan_forward minus the workspace: the scratch is a
  * file-scope device array of MV_STATIC_SCRATCH_BYTES inside the library (each GPU the library runs on holds its own
- * copy until the process ends; its address is resolved once per device in mv_hifigan_create).  The call allocates
+ * copy until the process ends; its address is resolved once per device, in mv_hifigan_create, and if the runtime could
+ * not resolve it this call -- not the create -- returns MV_EHIP).  The call allocates
  * nothing (no hipMalloc / hipFree, no allocating library routine) and returns MV_ENOMEM, launching nothing, when
  * mv_workspace_bytes(h, B, Tmax) exceeds the buffer: B * Tmax <= ~403 frames for config_v1 (~166 KB per frame),
  * i.e. 4.7 s of audio per call.  All calls on one GPU share that GPU's array and it keeps the last call's

@@ -270,18 +270,24 @@ def create_postnet(cfg: mv_postnet_cfg, state, device_index: int, precision: int
     return Handle(out.value, "postnet")
 
 
+WORKSPACE_CACHE_SLOTS = 4  # scratch tensors kept per model: least recently used ones beyond that are dropped
+
+
 def workspace(cache: dict, dev, nbytes: int):
     """Scratch tensor for one forward/infer call, cached per (device, current stream): two calls in flight on
     different streams never share a buffer, and one stream's calls are ordered anyway.  (A handle itself is
-    read-only in forward/infer; only mv_profile_* mutate it.)"""
+    read-only in forward/infer; only mv_profile_* mutate it.)  The cache keeps the WORKSPACE_CACHE_SLOTS most recently
+    used entries: a caller that makes a stream per request does not pile up one workspace per dead stream (a dropped
+    tensor goes back to torch's caching allocator, which keeps it alive for work still queued on its stream)."""
     import torch
 
     key = (dev, torch.cuda.current_stream(dev).cuda_stream)
-    ws = cache.get(key)
+    ws = cache.pop(key, None)
     if ws is None or ws.numel() < nbytes:
-        cache.pop(key, None)
         ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=dev)
-        cache[key] = ws
+    cache[key] = ws  # (re-inserted last: dicts keep insertion order, so the first key is the least recently used)
+    while len(cache) > WORKSPACE_CACHE_SLOTS:
+        cache.pop(next(iter(cache)))
     return ws
 
 

@@ -68,16 +68,22 @@ def shard_buckets(buckets, world):
 
 def pad_bucket(mels, bucket, pad_value=synth.MEL_PAD_VALUE, device=None, into=None):
     """Right-pad the bucket's mels ([80,T] tensors / arrays) to [B,80,Tmax] plus an int32 length vector.
-    `into`: a flat float32 tensor (e.g. a reusable pinned staging buffer) to build the batch in."""
+    `into`: a flat float32 tensor (e.g. a reusable pinned staging buffer) to build the batch in.
+    Each row is written once -- its mel, then the pad value behind it -- through a numpy view of the batch (one slice
+    copy per utterance with the GIL released for its duration: ~20 us per utterance, 50 k utterances/s per host thread,
+    against ~3 k/s that one GPU consumes; measured by tests/test_host_logic.py at 1 and 8 processes)."""
     B, tmax = len(bucket.indices), bucket.tmax
     n_mels = int(mels[bucket.indices[0]].shape[0])
     if into is not None:
         x = into[: B * n_mels * tmax].view(B, n_mels, tmax)
-        x.fill_(float(pad_value))
     else:
-        x = torch.full((B, n_mels, tmax), float(pad_value), dtype=torch.float32)
+        x = torch.empty((B, n_mels, tmax), dtype=torch.float32)
+    xn = x.numpy()
     for b, (i, T) in enumerate(zip(bucket.indices, bucket.lengths)):
-        x[b, :, :T] = torch.as_tensor(mels[i], dtype=torch.float32)[:, :T]
+        m = mels[i]
+        xn[b, :, :T] = (m.detach().cpu().numpy() if isinstance(m, torch.Tensor) else m)[:, :T]
+        if T < tmax:
+            xn[b, :, T:] = pad_value
     lengths = torch.tensor(bucket.lengths, dtype=torch.int32)
     if device is not None:
         x, lengths = x.to(device), lengths.to(device)
@@ -156,7 +162,8 @@ def synthesize_shard(vocoder, mels, lengths=None, rank=0, world=1, device=None, 
             host = wav.cpu().numpy()  # the D->H copy is part of the driver's work (do_syn.py:393)
             for b, (i, T) in enumerate(zip(bk.indices, bk.lengths)):
                 a = host[b, : T * hop]
-                stats.checksum += float(np.abs(a.astype(np.float64)).sum())
+                stats.checksum += (float(np.abs(a.astype(np.int32)).sum(dtype=np.int64)) if a.dtype == np.int16
+                                   else float(np.abs(a.astype(np.float64)).sum()))
                 if sink is not None:
                     sink(i, a)
                 elif keep_audio:

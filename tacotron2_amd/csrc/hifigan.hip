@@ -799,8 +799,11 @@ int mv_hifigan_create(const mv_hifigan_cfg* cfg, const mv_tensor* weights, int n
     rc = init_kernel_attributes();
     if (rc) return rc;
     if ((rc = init_fused_attributes())) return rc;
-    void* sp = nullptr;  // resolve this device's static scratch now, so that mv_hifigan_forward_static never has to
-    if ((rc = static_scratch_ptr(device, &sp))) return rc;
+    // this device's static scratch is resolved here (device current, no stream work pending) so that
+    // mv_hifigan_forward_static finds it in a table; a failure is NOT this call's failure -- callers that never use
+    // the static entry point lose nothing, and mv_hifigan_forward_static reports MV_EHIP itself
+    void* sp = nullptr;
+    (void)static_scratch_ptr(device, &sp);
     WeightMap W;
     if ((rc = W.load(weights, n_weights))) return rc;
     HifiganHandle* h = new HifiganHandle();

@@ -38,7 +38,7 @@ def write_parameter_file(path, mel, num=22050, den=256):
     outputs.write_parameter_file(path, np.asarray(mel, np.float32).T, num / den)
 
 
-def build_vocoder(name, device, dtype):
+def build_vocoder(name, device, dtype, unsafe_pickle=False):
     if name == "synthetic-hifigan":
         from .hifigan import AttrDict, Generator
 
@@ -54,7 +54,7 @@ def build_vocoder(name, device, dtype):
         m.eval().to(device)
         m.precision = dtype
         return vocoder.Vocoder("WAVEGLOW", m, sigma=0.666)
-    v = vocoder.load_vocoder(name, device=device, precision=dtype)
+    v = vocoder.load_vocoder(name, device=device, precision=dtype, unsafe_pickle=unsafe_pickle)
     if v is None:
         raise SystemExit(1)
     return v
@@ -67,6 +67,9 @@ def main(argv=None):
     ap.add_argument("--n", type=int, default=1000, help="synthetic corpus size when --mels is not given")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "fp32", "bf16x3"])
+    ap.add_argument("--unsafe_pickle", action="store_true",
+                    help="load a WaveGlow checkpoint as the reference does (torch.load weights_only=False, do_syn.py:148) "
+                         "instead of under the allow-listed unpickler: only for files you trust")
     ap.add_argument("--max_batch", type=int, default=32)
     ap.add_argument("--width", type=int, default=64, help="max frame spread inside a bucket")
     ap.add_argument("--out_dir", default=None)

@@ -124,8 +124,17 @@ def load_vocoder(path, device="cuda", hifigan_config=None, precision=None, sigma
             if unsafe_pickle:
                 ckpt = torch.load(path, map_location="cpu", weights_only=False)
             else:
-                with torch.serialization.safe_globals(_waveglow_pickle_allowlist(_glow)):
-                    ckpt = torch.load(path, map_location="cpu", weights_only=True)
+                import pickle
+
+                try:
+                    with torch.serialization.safe_globals(_waveglow_pickle_allowlist(_glow)):
+                        ckpt = torch.load(path, map_location="cpu", weights_only=True)
+                except pickle.UnpicklingError as e:
+                    # the reference loads the same file with weights_only=False (do_syn.py:148) and would accept it
+                    raise RuntimeError(
+                        f"{path}: the checkpoint pickles an object outside the WaveGlow allow-list ({e}).  If the file "
+                        f"comes from a source you trust, load it as the reference does: load_vocoder(..., "
+                        f"unsafe_pickle=True), or --unsafe_pickle on the do_syn_batch / do_syn_e2e command line") from e
         finally:
             if not had_path and GLOW_PATH in sys.path:
                 sys.path.remove(GLOW_PATH)

@@ -4,6 +4,7 @@ import copy
 import os
 import re
 import sys
+import time
 import wave
 
 import numpy as np
@@ -228,3 +229,80 @@ def test_bench_gpus_flag_starts_that_many_ranks():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run"], env=env1,
                        capture_output=True, text=True, timeout=240)
     assert p.returncode == 0 and json.loads(p.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
+def test_bench_launcher_ends_the_run_when_a_rank_dies():
+    """A rank that exits before the rendezvous must not leave rank 0 waiting for the store's timeout: the launcher
+    polls every child, kills the survivors and exits non-zero within seconds."""
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["BENCH_DRY_RUN_FAIL_RANK"] = "1"
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env,
+                       capture_output=True, text=True, timeout=240)
+    assert p.returncode == 1 and "rank 1 exited with 3" in p.stderr, p.stderr[-500:]
+    assert time.time() - t0 < 120
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]  # no result line from a broken run
+
+
+class _PassThroughVocoder:
+    """What the host sees of a GPU vocoder: int16 [B, 256 T] handed back without computing anything (a view of one
+    reusable buffer, as the pinned download slots are), so that only the host-side work of a rank is timed."""
+    hop = 256
+
+    def __init__(self):
+        self.buf = torch.zeros(32 * 1024 * 256, dtype=torch.int16)
+
+    def __call__(self, mel, lengths=None, out="pcm16"):
+        B, _, T = mel.shape
+        return self.buf[: B * T * 256].view(B, T * 256)
+
+
+def _host_rate_main(rank, world, n, q):
+    torch.set_num_threads(1)
+    lens = synth.synthetic_lengths(n, 1234)
+    base = [synth.synthetic_mel(int(lens.max()), 7 + i) for i in range(4)]
+    mels = [base[i % 4][:, : int(T)] for i, T in enumerate(lens)]
+    seen = [0]
+
+    def sink(i, pcm):
+        seen[0] += int(pcm.shape[0])
+
+    t0 = time.perf_counter()
+    _, st = batch.synthesize_shard(_PassThroughVocoder(), mels, [int(t) for t in lens], rank=rank, world=world, sink=sink)
+    dt = time.perf_counter() - t0
+    q.put((rank, st.utterances, st.frames, seen[0], dt))
+
+
+def test_host_side_of_eight_ranks_on_the_configs3_corpus():
+    """BASELINE configs[3] is 10 000 utterances over 8 ranks of ONE host.  Everything a rank does on the host per
+    utterance -- bucket, pad into the staging buffer, hand the PCM view to the sink, account -- with the vocoder
+    replaced by a pass-through: utterances per second per process at 1 and at 8 processes.  One MI355X consumes
+    ~3 000 utterances of this corpus per second (17.5 k audio-s/s over 5.9 s each); the host path of a rank must
+    stay well above that with all eight running, or it -- not the GPUs -- bends the scaling curve."""
+    import torch.multiprocessing as mp
+
+    n = 10000
+    ctx = mp.get_context("spawn")
+    rates = {}
+    for world in (1, 8):
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_host_rate_main, args=(r, world, n, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        outs = [q.get(timeout=300) for _ in procs]
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+        assert sum(o[1] for o in outs) == n  # the shards cover the corpus exactly once ...
+        assert all(o[3] == o[2] * 256 for o in outs)  # ... and every rank's sink saw every sample of its shard
+        frames = [o[2] for o in outs]
+        assert (max(frames) - min(frames)) / (sum(frames) / world) < 0.02  # LPT: loads within 2 % of each other
+        rates[world] = sorted(o[1] / o[4] for o in outs)
+    print("host path, utterances/s per process: 1 process %.0f; 8 processes min %.0f median %.0f (os.cpu_count() = %d)"
+          % (rates[1][0], rates[8][0], rates[8][4], os.cpu_count() or 0))
+    assert rates[1][0] >= 3000.0
+    if (os.cpu_count() or 1) >= 8:  # (with fewer cores than ranks the processes time-share)
+        assert rates[8][0] >= 1500.0

@@ -67,3 +67,46 @@ def test_static_scratch_rejects_what_does_not_fit():
     rc = _native.lib().mv_hifigan_forward_static(h.ptr, mel.data_ptr(), None, 2 ** 30, 2 ** 30, wav.data_ptr(),
                                                  _native.OUT_F32, None)
     assert rc == -4
+
+
+def test_static_entry_point_allocates_nothing_and_is_legal_under_capture():
+    """The property the entry point exists for: the call leaves the device's free memory where it was, and it can be
+    captured into a HIP graph on a side stream (under capture hipMalloc is illegal) whose replay equals the eager
+    call.  An out-of-range `lengths` entry is clamped on the device here as everywhere."""
+    st = synth.hifigan_state(synth.HIFIGAN_V1, 0)
+    h = _native.create_hifigan(synth.HIFIGAN_V1, st, 0, _native.PREC_BF16)
+    lib = _native.lib()
+    mel = torch.from_numpy(np.stack([synth.synthetic_mel(48, 31), synth.synthetic_mel(48, 32)])).cuda()
+    ld = torch.tensor([48, 10 ** 6], dtype=torch.int32, device="cuda")  # the second entry is out of range: clamped to 48
+    eager = torch.zeros((2, 48 * 256), dtype=torch.int16, device="cuda")
+    replayed = torch.zeros_like(eager)
+    want = _call(h, mel, [48, 48], True, static=False)
+
+    def call(out, stream):
+        rc = lib.mv_hifigan_forward_static(h.ptr, mel.data_ptr(), ld.data_ptr(), 2, 48, out.data_ptr(), _native.OUT_PCM16,
+                                           stream)
+        _native.check(rc, "mv_hifigan_forward_static")
+
+    call(eager, None)  # (first call on this handle: anything one-time has happened before the measurement)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    call(eager, None)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free1 == free0, (free0, free1)
+    assert np.array_equal(eager.cpu().numpy(), want)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        call(replayed, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert not replayed.any()  # captured, not run
+    g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(replayed.cpu().numpy(), want)
+    replayed.zero_()
+    g.replay()  # a graph is there to be replayed
+    torch.cuda.synchronize()
+    assert np.array_equal(replayed.cpu().numpy(), want)
