@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel clock, MFMA-pipe utilisation and hardware FLOP rate from one rocprofv3 --pmc pass that
-holds SQ_VALU_MFMA_BUSY_CYCLES, SQ_INSTS_VALU_MFMA_MOPS_BF16 and GRBM_GUI_ACTIVE.
+holds SQ_VALU_MFMA_BUSY_CYCLES, SQ_INSTS_VALU_MFMA_MOPS_BF16 (or _F16 for MV_PREC_F16 runs) and GRBM_GUI_ACTIVE.
   clock     = GRBM_GUI_ACTIVE / 8 XCDs / kernel time          (MI355X_MICROARCH.md, DVFS give-back)
   MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)
   hw FLOP/s = SQ_INSTS_VALU_MFMA_MOPS_BF16 * 512 / kernel time (executed, halo recompute included)
@@ -31,7 +31,8 @@ def main(path):
             continue
         print("%s,%d,%.3f,%.2f,%.1f,%.0f" % (k, n[k], d * 1e3, g / d / 1e9,
                                              100 * c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024 * g),
-                                             c.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0) * 512 / d / 1e12))
+                                             (c.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0) +
+                                              c.get("SQ_INSTS_VALU_MFMA_MOPS_F16", 0.0)) * 512 / d / 1e12))
 
 
 if __name__ == "__main__":

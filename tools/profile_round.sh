@@ -15,7 +15,7 @@ pass() {  # name counters...
     local name=$1; shift
     timeout -s KILL 120 rocprofv3 --pmc "$@" -d "$out/pmc_$name" -o pmc --output-format csv -- $BENCH > "$out/pmc_$name.log" 2>&1
 }
-pass sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAIT_INST_ANY SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE
+pass sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES ${MFMA_MOPS:-SQ_INSTS_VALU_MFMA_MOPS_BF16} SQ_WAIT_INST_ANY SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE
 pass fetch FETCH_SIZE GRBM_GUI_ACTIVE
 pass write WRITE_SIZE TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE
 cd "$root"
