@@ -76,7 +76,7 @@ def parse(argv=None):
 
 # ---------------------------------------------------------------------------------------------------------
 # launcher: `python bench.py --gpus N` without torch.distributed.run
-def count_gpus_without_hip():
+def count_gpus_without_hip(topology="/sys/class/kfd/kfd/topology/nodes"):
     """GPU nodes of this machine WITHOUT touching HIP in this process (the launcher must not have initialised the GPU when
     it starts its children): the KFD topology in sysfs lists every node with its SIMD count (CPUs have none) -- narrowed
     by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when they are set; if sysfs is not readable, a throw-away child process
@@ -85,7 +85,7 @@ def count_gpus_without_hip():
 
     n = 0
     found = False
-    for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+    for path in glob.glob(os.path.join(topology, "*", "properties")):
         try:
             with open(path) as f:
                 props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)

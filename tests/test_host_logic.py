@@ -247,6 +247,35 @@ def test_bench_launcher_ends_the_run_when_a_rank_dies():
     assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]  # no result line from a broken run
 
 
+def test_bench_counts_gpus_from_the_kfd_topology_without_hip(tmp_path, monkeypatch):
+    """The launcher must know how many GPUs the node has BEFORE it starts its children and WITHOUT initialising HIP in
+    its own process: it reads the KFD topology (CPU nodes have simd_count 0) and honours *_VISIBLE_DEVICES."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    for i, simd in enumerate((0, 0, 1024, 1024, 1024)):  # two CPU nodes, three GPUs
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / "properties").write_text(f"cpu_cores_count {64 if simd == 0 else 0}\nsimd_count {simd}\nmem_banks_count 1\n")
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert bench.count_gpus_without_hip(str(tmp_path)) == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert bench.count_gpus_without_hip(str(tmp_path)) == 2
+    assert "torch" not in bench.count_gpus_without_hip.__code__.co_names  # (no torch call on the sysfs path)
+
+
+def test_bench_prices_waveglow_with_the_references_flops():
+    """WaveGlow-512 costs 65 338 996 FLOP per sample = 1.4407 TFLOP per audio second in the
+    reference's formulation; bench.py's `frac_of_mfma_roofline_reference_flops` uses exactly that count."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    macs = bench.waveglow_reference_macs_per_frame(synth.WAVEGLOW_512)
+    assert abs(2.0 * macs / 256 - 65338996) <= 64  # FLOP per sample
+    assert abs(2.0 * macs * 22050 / 256 / 1e12 - 1.4407) < 1e-4
+
+
 class _PassThroughVocoder:
     """What the host sees of a GPU vocoder: int16 [B, 256 T] handed back without computing anything (a view of one
     reusable buffer, as the pinned download slots are), so that only the host-side work of a rank is timed."""
