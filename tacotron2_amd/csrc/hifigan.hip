@@ -378,6 +378,20 @@ int launch_convT(const Layer& L, const void* x, long long x_bs, int cin_stride, 
     return launch_layer(L, &sb, 1, a, stream, prof);
 }
 
+#ifdef MV_SWEEP_CFG
+// Diagnostic builds only (tools/sweep_cfg.sh): tile configuration of conv_pre (index 0) and of upsampler i (index i + 1)
+// from the environment, "MV_SWEEP_CFG=pre,u0,u1,u2,u3" (-1 = the default).  The product library reads no environment.
+static int sweep_cfg(int idx) {
+    const char* e = getenv("MV_SWEEP_CFG");
+    if (!e) return -1;
+    int v[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+    sscanf(e, "%d,%d,%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], &v[7]);
+    return idx < 8 ? v[idx] : -1;
+}
+#else
+static int sweep_cfg(int) { return -1; }
+#endif
+
 static int hifigan_build(HifiganHandle* h, WeightMap& W) {
     const mv_hifigan_cfg& c = h->cfg;
     const int bf16 = h->precision;  // MV_PREC_* as the layer builders take it
@@ -399,7 +413,7 @@ static int hifigan_build(HifiganHandle* h, WeightMap& W) {
         if ((rc = conv_shape_check(w, h->C[0], c.num_mels, 7, "conv_pre.weight"))) return rc;
         const HostTensor* b = W.get("conv_pre.bias");
         if ((rc = bias_check(b, h->C[0], "conv_pre.bias"))) return rc;
-        if ((rc = build_conv1d_layer(&h->pre, w, b, c.num_mels, h->C[0], 7, 1, h->melp, h->Cp[0], bf16))) return rc;
+        if ((rc = build_conv1d_layer(&h->pre, w, b, c.num_mels, h->C[0], 7, 1, h->melp, h->Cp[0], bf16, sweep_cfg(0)))) return rc;
         h->pre.alg_macs_per_n = (double)h->C[0] * c.num_mels * 7;
         macs += (double)h->C[0] * c.num_mels * 7;
     }
@@ -418,7 +432,7 @@ static int hifigan_build(HifiganHandle* h, WeightMap& W) {
         snprintf(name, sizeof name, "ups.%d.bias", i);
         const HostTensor* b = W.get(name);
         if ((rc = bias_check(b, h->C[i + 1], name))) return rc;
-        if ((rc = build_convT_layer(&h->ups[i], w, b, h->C[i], h->C[i + 1], K, u, h->Cp[i], h->Cp[i + 1], bf16)))
+        if ((rc = build_convT_layer(&h->ups[i], w, b, h->C[i], h->C[i + 1], K, u, h->Cp[i], h->Cp[i + 1], bf16, sweep_cfg(i + 1))))
             return rc;
         h->ups[i].alg_macs_per_n = (double)h->C[i] * h->C[i + 1] * K;
         macs += rows * (double)h->C[i] * h->C[i + 1] * K;  // every input row meets all K taps
