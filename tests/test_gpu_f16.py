@@ -46,6 +46,20 @@ def test_hifigan_f16_against_reference_golden(golden_dir, name, T):
     assert np.array_equal(pcm, (32768.0 * y).astype(np.int32).astype(np.int16))
 
 
+def test_hifigan_f16_against_the_oracles_float16_model():
+    """The C oracle with float16-rounded operands (fp32 accumulate, fp32 residual: mode 2) is the model of what the
+    kernels compute; the library differs from it only by the float16 storage between kernels and summation order."""
+    from oracle import c_oracle
+
+    st = synth.hifigan_state(synth.HIFIGAN_V1, 0)
+    mel = synth.synthetic_mel(40, 77)
+    y = _gen("f16")(torch.from_numpy(mel[None]).cuda())[0, 0].cpu().numpy()
+    model = c_oracle.hifigan_forward(st, synth.HIFIGAN_V1, mel, bf16_operands=2)
+    exact = c_oracle.hifigan_forward(st, synth.HIFIGAN_V1, mel)
+    assert _snr(exact, y) >= F16_BAR_DB and _snr(exact, model) >= F16_BAR_DB
+    assert _snr(model, y) >= F16_BAR_DB  # (errors of the same size, largely uncorrelated: storage rounding, order)
+
+
 def test_hifigan_f16_margin():
     worst = (1e9, None)
     for seed, heavy in CASES:
