@@ -122,3 +122,23 @@ def test_full_size_bf16_against_fp32_mode(lengths):
     for b, n in enumerate(lengths):
         assert _snr(ref[b, :n * 256], got[b, :n * 256]) >= 40.0, (b, _snr(ref[b, :n * 256], got[b, :n * 256]))
         assert not got[b, n * 256:].any() and not ref[b, n * 256:].any()
+
+
+def test_full_width_fp32_against_the_oracle():
+    """BASELINE.json configs[2]'s model -- 512 channels, 12 flows, sigma 0.666 -- on a 250-frame mel (8000 steps: 32-63
+    row tiles per launch) in fp32 against the oracle (oracle/torch_ref.py on this box's host cores, pinned to the
+    reference by tests/test_oracle_golden.py at 512 channels and T = 64): the full-width result the bf16 tests above
+    lean on is held against the reference's arithmetic directly, at the fp32 bar.  (Half of configs[2]'s 500 frames:
+    the oracle takes ~45 s of CPU for these; the kernels' work per row does not depend on the length.)"""
+    from oracle import torch_ref
+
+    cfg = _cfg(512)
+    T = 250
+    st = synth.waveglow_state(cfg, 0)
+    mel = synth.synthetic_mel(T, 1234)[None]
+    noise = synth.waveglow_noise(cfg, 1, T, 1234)
+    ref = torch_ref.waveglow_infer(st, cfg, mel, noise, 0.666).numpy()
+    m = _model(cfg, 0, "fp32")
+    y = m.infer(torch.from_numpy(mel).cuda(), sigma=0.666, noise=[torch.from_numpy(n) for n in noise]).cpu().numpy()
+    assert y.shape == ref.shape == (1, 256 * T)
+    assert float(np.abs(y - ref).max()) <= 1e-3, float(np.abs(y - ref).max())
