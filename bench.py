@@ -404,15 +404,17 @@ def sharded_record(torch, dist, dev, rank, world, dtype):
 def snr_record(torch, dev):
     """Worst per-utterance SNR of the 16-bit-operand modes on the bench batch against the library's fp32 mode (which the
     goldens pin to the reference at <= 1e-3): BASELINE's bar is >= 40 dB."""
-    out = {}
-    ref = None
+    from tacotron2_amd import synth
+
+    lengths = np.sort(synth.synthetic_lengths(32, 1234))[::-1]  # the batch build_model makes for rank 0
+    out, ref = {}, None
     for dtype in ("fp32", "bf16", "f16"):
         m, run, _, _, _ = build_model(torch, "hifigan", dtype, None, 0, dev)
         y = run()[:, 0].double()
         torch.cuda.synchronize()
+        del m, run
         if ref is None:
             ref = y
-            lengths = np.sort(__import__("tacotron2_amd.synth", fromlist=["x"]).synthetic_lengths(32, 1234))[::-1]
             continue
         worst = 1e9
         for b, T in enumerate(lengths):
@@ -421,7 +423,6 @@ def snr_record(torch, dev):
             den = max(float(((ref[b, :n] - y[b, :n]) ** 2).sum()), 1e-300)
             worst = min(worst, 10.0 * np.log10(num / den))
         out[dtype] = round(float(worst), 2)
-        del m, run
     torch.cuda.empty_cache()
     return out
 
